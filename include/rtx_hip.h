@@ -1,0 +1,164 @@
+/*
+ * rtx_hip.h -- C ABI of librtx_hip.so: the MI355X (gfx950) implementation of the
+ * Scene::render() hot path of Schatten2021/rust-raytracing (crate `rtx` 0.1.0).
+ *
+ * The reference has no FFI of its own (no `extern`, no `unsafe`); the boundary this library
+ * replaces is the Rust method
+ *     Scene::render(&self, width: usize, height: usize) -> Vec<Vec<Vector3>>
+ *                                                         (src/raytracing/scene.rs:144-170)
+ * and everything below it: render_pixel / get_ray_dir / render_ray / closest_object / ray_hit /
+ * random_bounce_dir (scene.rs:194-292), Object::distance / normal_at (object.rs:37-51),
+ * Sphere / Plane / Triangle distance + normal (object/sphere.rs:19-33, plane.rs:20-35,
+ * triangle.rs:20-127) and the Vector3 ops they use (src/math/vector*.rs).  A Rust shim
+ * binds these entry points with a plain `extern "C"` block (INTEGRATION.md shows it).
+ *
+ * Plain C: fixed-width integers, doubles, caller-owned memory, no C++ or torch types.
+ * All entry points return 0 on success; on failure they return a non-zero RtxStatus and
+ * rtx_last_error() (thread-local) describes the failure.  There is NO CPU fallback: without
+ * a usable gfx950 device every render entry point fails with RTX_ERR_NO_DEVICE.
+ */
+#ifndef RTX_HIP_H
+#define RTX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_HIP_VERSION 100  /* 0.1.0, the crate version this drop-in tracks (Cargo.toml:3) */
+
+typedef enum RtxStatus {
+    RTX_OK = 0,
+    RTX_ERR_INVALID_ARGUMENT = 1,
+    RTX_ERR_NO_DEVICE = 2,       /* no HIP device / not gfx950 */
+    RTX_ERR_HIP = 3,             /* a HIP runtime call failed; see rtx_last_error() */
+    RTX_ERR_UNSUPPORTED = 4,     /* e.g. an object kind the device path has no primitive for */
+    RTX_ERR_OUT_OF_MEMORY = 5
+} RtxStatus;
+
+/* Shape tags of the three built-in shapes (object/sphere.rs, plane.rs, triangle.rs).
+ * User-defined CustomShape impls (object.rs:53-76) have no device primitive -> RTX_ERR_UNSUPPORTED. */
+enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_TRIANGLE = 2 };
+
+/* Kernel selection (RtxConfig.kernel). */
+enum {
+    RTX_KERNEL_AUTO  = 0,  /* = RTX_KERNEL_MIXED */
+    RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
+    RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
+                              produces the same bits as RTX_KERNEL_EXACT */
+    RTX_KERNEL_MIXED_VERIFY = 3 /* debug: MIXED that also runs the exact sweep per segment and counts
+                              disagreements in RtxStats.filter_mismatches (must stay 0) */
+};
+
+/* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)
+ * with Material{base_color, emission_color, roughness} (object.rs:78-86).  136 bytes. */
+typedef struct RtxObject {
+    uint32_t kind;               /* RTX_SPHERE | RTX_PLANE | RTX_TRIANGLE */
+    uint32_t reserved;           /* must be 0 */
+    double   geom[9];            /* sphere: position.xyz, radius           (sphere.rs:9-12)
+                                    plane:  position.xyz, normal.xyz       (plane.rs:9-12)
+                                    triangle: vertices[0..3].xyz           (triangle.rs:9-11) */
+    double   base_color[3];
+    double   emission_color[3];
+    double   roughness;
+} RtxObject;
+
+/* Config (scene.rs:16-28) plus the two fields the build adds. */
+typedef struct RtxConfig {
+    uint64_t rays_per_pixel;
+    uint64_t max_bounces;
+    double   focal_length;
+    double   focal_offset;
+    double   non_focal_offset;
+    uint64_t seed;               /* counter-RNG key; the reference's fastrand stream is unseedable */
+    uint32_t kernel;             /* RTX_KERNEL_* */
+    uint32_t reserved;           /* must be 0 */
+} RtxConfig;
+
+/* Camera (camera.rs:7-15).  to_world_space / to_cam_space are the three ROWS of each matrix
+ * (mat.rs:11-18), row-major.  Only fov, position and to_world_space are read by render
+ * (scene.rs:145,196,214-221; camera.rs:65-67). */
+typedef struct RtxCamera {
+    double fov;
+    double position[3];
+    double direction[3];
+    double to_cam_space[9];
+    double to_world_space[9];
+} RtxCamera;
+
+/* Scene (scene.rs:78-85). */
+typedef struct RtxScene {
+    RtxConfig        config;
+    RtxCamera        camera;
+    uint64_t         n_objects;
+    const RtxObject *objects;    /* Scene.objects, in order (order decides ties, scene.rs:250) */
+} RtxScene;
+
+/* Counters of one render call (optional out-parameter). */
+typedef struct RtxStats {
+    uint64_t primary_rays;       /* rows * width * rays_per_pixel */
+    uint64_t segments;           /* closest_object queries (scene.rs:231) */
+    uint64_t exact_tests;        /* f64 shape evaluations (EXACT: segments * n_objects) */
+    uint64_t filter_tests;       /* f32 filter evaluations (MIXED only) */
+    double   trace_ms;           /* device time of the trace kernel(s), hipEvent on the launch stream */
+    double   resolve_ms;         /* device time of the per-pixel sample fold */
+    uint64_t filter_mismatches;  /* RTX_KERNEL_MIXED_VERIFY only */
+    uint32_t trace_launches;
+    uint32_t reserved;
+} RtxStats;
+
+typedef struct RtxSceneHandle_ *RtxSceneHandle;
+
+/* -- library ----------------------------------------------------------------------------- */
+int32_t     rtx_version(void);
+const char *rtx_last_error(void);
+int32_t     rtx_device_count(void);     /* number of usable gfx950 devices (0 when none) */
+
+/* Camera::new (camera.rs:19-28, derive_to_world_space_mat :42-49, Mat3x3::inverse
+ * specific_math.rs:10-14).  Host-side, f64, reference operation order. */
+int32_t rtx_camera_new(const double position[3], const double direction[3], double fov, RtxCamera *out);
+
+/* Scene::render (scene.rs:144-170).  out_rgb: height*width*3 doubles, out_rgb[(y*width+x)*3+c]
+ * == reference img[y][x].{x,y,z}; unclamped; row 0 is the reference's row 0.
+ * Uploads the scene to device 0, renders, copies back. */
+int32_t rtx_render(const RtxScene *scene, uint32_t width, uint32_t height, double *out_rgb);
+
+/* Scene::render_to_image (scene.rs:172-178): `* 256`, saturating `as u8`, vertical flip.
+ * out_rgb8: height*width*3 bytes. */
+int32_t rtx_render_to_image(const RtxScene *scene, uint32_t width, uint32_t height, uint8_t *out_rgb8);
+
+/* -- split form: upload once, render many (rows / devices), output stays on the device ------ */
+int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *out);
+int32_t rtx_scene_free(RtxSceneHandle scene);
+
+/* Replace the Config of an uploaded scene (rays_per_pixel, seed, kernel, ...). */
+int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config);
+
+/*
+ * Renders image rows row_begin, row_begin+row_stride, ... (n_rows of them, all < height) of the
+ * width x height image into d_out_rgb, a DEVICE buffer of n_rows*width*3 doubles (row k of the
+ * buffer is image row row_begin + k*row_stride).  Pixel values do not depend on the
+ * partition: a pixel's RNG key is its index in the full image.  stream is a hipStream_t
+ * (NULL = the device's null stream).  The call enqueues all work on `stream`; it returns
+ * after the work is enqueued when stats == NULL, and after it completed (stream
+ * synchronised, stats filled) otherwise.
+ */
+int32_t rtx_render_rows(RtxSceneHandle scene, uint32_t width, uint32_t height,
+                        uint32_t row_begin, uint32_t row_stride, uint32_t n_rows,
+                        double *d_out_rgb, void *stream, RtxStats *stats);
+
+/* Device epilogue of render_to_image on a full device image (scene.rs:175-178):
+ * d_rgb height*width*3 doubles -> d_rgb8 height*width*3 bytes, flipped vertically. */
+int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t height,
+                                  uint8_t *d_rgb8, int32_t device, void *stream);
+
+/* Test hook: evaluates one f64 operation per element on the device (op 0: a/b, 1: sqrt(a),
+ * 2: sin(a), 3: cos(a)); a, b, out are HOST arrays of n doubles.  Used by tests/ to check that the
+ * device's / and sqrt are correctly rounded and to measure how far its sin/cos are from libm. */
+int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,137 @@
+/*
+ * rtx_oracle.h -- CPU oracle for the Scene::render hot path of Schatten2021/rust-raytracing.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C, IEEE-f64 restatement of the reference's CPU
+ * path-tracing loop.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it -- as the checker, never as the product.  The product path
+ * (rust-raytracing_amd/csrc, librtx_hip.so) never links, loads or calls anything in oracle/.
+ *
+ * PARITY PINNING.  The reference is Rust and cannot be compiled here (no rustc/cargo), so no
+ * oracle/_ref build exists.  The reference's own tests hold exactly four known-answer tests
+ * (src/raytracing/camera.rs:82-109, 12 vector equalities); the oracle is pinned against all of
+ * them (tests/test_oracle_kats.py).  Everything else on the path (intersection, shading,
+ * sampling, averaging) is NOT pinned by any reference test or fixture: "parity unpinned" beyond
+ * the camera basis.  Randomness: the reference draws from fastrand 2.3.0's thread-local,
+ * never-seeded WyRand on one OS thread per row (src/math/vector.rs:31-38, scene.rs:151), which
+ * is not reproducible even between two runs of the reference itself.  The oracle keeps the
+ * reference's draw ORDER and output distribution (52-bit mantissa uniform on [0,1)) but takes
+ * the draws from a counter-based generator keyed on (seed, pixel, sample, draw index), so
+ * the HIP kernel can reproduce them bit-for-bit.
+ *
+ * Every function cites the reference file:line it follows.  Compile with -ffp-contract=off:
+ * Rust never fuses a*b+c, and neither may this file.
+ */
+#ifndef RTX_ORACLE_H
+#define RTX_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double x, y, z; } rtxo_vec3;            /* src/math/vector.rs:12-20 */
+typedef struct { rtxo_vec3 x, y, z; } rtxo_mat3;         /* rows; src/math/mat.rs:10-18 */
+
+typedef struct {                                         /* src/raytracing/camera.rs:7-15 */
+    double    fov;
+    rtxo_vec3 position;
+    rtxo_vec3 direction;
+    rtxo_mat3 to_cam_space;
+    rtxo_mat3 to_world_space;
+} rtxo_camera;
+
+typedef struct {                                         /* src/raytracing/scene.rs:16-28 + seed */
+    uint64_t rays_per_pixel;
+    uint64_t max_bounces;
+    double   focal_length;
+    double   focal_offset;
+    double   non_focal_offset;
+    uint64_t seed;                                       /* build-added: counter-RNG key */
+} rtxo_config;
+
+enum { RTXO_SPHERE = 0, RTXO_PLANE = 1, RTXO_TRIANGLE = 2 };
+
+typedef struct {                                         /* object.rs:9-15 + :78-86 flattened */
+    uint32_t kind;
+    uint32_t pad_;
+    double   geom[9];        /* sphere: c.xyz, r | plane: pos.xyz, normal.xyz | triangle: v0,v1,v2 */
+    double   base_color[3];
+    double   emission_color[3];
+    double   roughness;
+} rtxo_object;
+
+typedef struct {
+    rtxo_config        config;
+    rtxo_camera        camera;
+    uint64_t           n_objects;
+    const rtxo_object *objects;                          /* scene order == Scene.objects order */
+} rtxo_scene;
+
+enum { RTXO_MODE_CLEAN = 0, RTXO_MODE_FAITHFUL = 1 };
+
+/* --- counter-based RNG shared bit-for-bit with the HIP kernel ------------------------------- */
+uint64_t rtxo_rng_key(uint64_t seed, uint64_t pixel_index, uint64_t sample_index);
+double   rtxo_rng_u01(uint64_t key, uint64_t draw_index);      /* fastrand::f64() distribution */
+
+/* --- math (src/math) ------------------------------------------------------------------------ */
+double    rtxo_dot(rtxo_vec3 a, rtxo_vec3 b);                    /* vector.rs:85-87 */
+rtxo_vec3 rtxo_cross(rtxo_vec3 a, rtxo_vec3 b);                  /* vector.rs:89-95 */
+double    rtxo_len(rtxo_vec3 a);                                 /* vector.rs:101-103 */
+rtxo_vec3 rtxo_norm(rtxo_vec3 a);                                /* vector.rs:105-107 */
+rtxo_vec3 rtxo_mat_mul_vec(const rtxo_mat3 *m, rtxo_vec3 v);     /* mat/mul.rs:42-50 */
+rtxo_mat3 rtxo_mat_transpose(const rtxo_mat3 *m);                /* mat/specific_math.rs:16-21 */
+rtxo_mat3 rtxo_mat_inverse(const rtxo_mat3 *m);                  /* mat/specific_math.rs:10-14 */
+
+/* --- camera (src/raytracing/camera.rs) ------------------------------------------------------- */
+void      rtxo_camera_new(rtxo_camera *cam, rtxo_vec3 position, rtxo_vec3 direction, double fov); /* :19-28 */
+void      rtxo_camera_set_direction(rtxo_camera *cam, rtxo_vec3 direction);                       /* :35-40 (lagging, as the reference) */
+rtxo_vec3 rtxo_camera_to_cam_space(const rtxo_camera *cam, rtxo_vec3 v);                          /* :51-53 */
+rtxo_vec3 rtxo_camera_to_world_space(const rtxo_camera *cam, rtxo_vec3 v);                        /* :55-57 */
+rtxo_vec3 rtxo_camera_rotate_to_world_space(const rtxo_camera *cam, rtxo_vec3 v);                 /* :65-67 */
+
+/* --- shapes: return 1 and *dst when the reference returns Some(dst), else 0 ------------------ */
+int       rtxo_sphere_distance(const double geom[4], rtxo_vec3 pos, rtxo_vec3 dir, double *dst);   /* sphere.rs:19-30 */
+rtxo_vec3 rtxo_sphere_normal(const double geom[4], rtxo_vec3 world_pos);                           /* sphere.rs:31-33 */
+int       rtxo_plane_distance(const double geom[6], rtxo_vec3 pos, rtxo_vec3 dir, double *dst);    /* plane.rs:20-31 */
+rtxo_vec3 rtxo_plane_normal(const double geom[6], rtxo_vec3 world_pos);                            /* plane.rs:33-35 */
+int       rtxo_triangle_distance(const double geom[9], rtxo_vec3 pos, rtxo_vec3 dir, double *dst); /* triangle.rs:108-127 */
+rtxo_vec3 rtxo_triangle_normal(const double geom[9], rtxo_vec3 world_pos);                         /* triangle.rs:104-107 */
+int       rtxo_triangle_contains(const double geom[9], rtxo_vec3 point);                           /* triangle.rs:37-101; -1 = "can't handle LGS" */
+
+/* --- object (src/raytracing/object.rs) -------------------------------------------------------- */
+int       rtxo_object_distance(const rtxo_object *o, rtxo_vec3 pos, rtxo_vec3 dir, double *dst);   /* object.rs:49-51 */
+rtxo_vec3 rtxo_object_normal_at(const rtxo_object *o, rtxo_vec3 world_pos);                        /* object.rs:37-39 */
+
+/* --- shading (src/raytracing/scene.rs) --------------------------------------------------------- */
+rtxo_vec3 rtxo_random_direction(double u_z, double u_theta);                                     /* vector.rs:36-45 */
+rtxo_vec3 rtxo_random_bounce_dir(rtxo_vec3 ray_dir, rtxo_vec3 normal, double roughness,
+                                 double u_z, double u_theta);                                    /* scene.rs:279-292 */
+/* closest_object (scene.rs:243-251): returns object index or -1 */
+int64_t   rtxo_closest_object(const rtxo_scene *s, rtxo_vec3 pos, rtxo_vec3 dir, double *dst);
+rtxo_vec3 rtxo_get_ray_dir(const rtxo_scene *s, double x, double y, double vertical_fov);        /* scene.rs:213-222 */
+/* render_pixel (scene.rs:194-212). pixel_index keys the RNG; *segments (optional) += closest_object calls */
+rtxo_vec3 rtxo_render_pixel(const rtxo_scene *s, double u, double v, double vertical_fov,
+                            uint64_t pixel_index, uint64_t *segments);
+
+/*
+ * Scene::render (scene.rs:144-170).  out_rgb is [height][width][3] doubles, row 0 first
+ * (same [y][x] indexing as the reference's Vec<Vec<Vector3>>).  segments (optional) is
+ * [height][width] closest_object-call counts.  Rows row_begin, row_begin+row_stride, ... are
+ * rendered (row_begin=0,row_stride=1 renders everything); others are left untouched.
+ *   mode RTXO_MODE_FAITHFUL: one OS thread per image row (scene.rs:151), a mutex per object
+ *       taken around every distance()/normal() call (object.rs:38,50); n_threads ignored.
+ *   mode RTXO_MODE_CLEAN: n_threads workers pulling rows from a shared counter, no locks.
+ * Returns 0 on success.
+ */
+int rtxo_render(const rtxo_scene *s, uint32_t width, uint32_t height,
+                uint32_t row_begin, uint32_t row_stride,
+                double *out_rgb, uint64_t *segments, int n_threads, int mode);
+
+/* render_to_image (scene.rs:172-178): x256, saturating `as u8`, vertical flip. */
+void rtxo_quantize_image(const double *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,365 @@
+"""Host-side mirror of the `rtx` crate's public surface (src/lib.rs:1-5) over librtx_hip.so.
+
+    rtx::Scene / Config / Camera            -> Scene, Config, Camera        (scene.rs, camera.rs)
+    rtx::object::{Object, Material, ...}    -> Object, Material, Sphere, Plane, Triangle (object.rs, object/*.rs)
+    rtx::math::Vector3                      -> Vector3                      (math/vector.rs)
+
+Same names, argument meaning and error behaviour as the reference where a Python host can
+express them; `Scene.render(width, height)` returns img[y][x] = (r, g, b) as a float64 array of
+shape (height, width, 3).  All rendering happens in hand-written HIP behind the C ABI of
+include/rtx_hip.h; this package is the test/bench harness's binding and never computes pixels
+itself.  (The literal drop-in for Rust callers is the extern "C" shim in INTEGRATION.md.)
+
+The directory is named `rust-raytracing_amd`; import it as `rust_raytracing_amd` (shim module at
+the repository root).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import abi
+from .abi import (OBJECT_DTYPE, RTX_KERNEL_AUTO, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY,
+                  RTX_PLANE, RTX_SPHERE, RTX_TRIANGLE, RtxError, load_library)
+
+__all__ = ["Vector3", "Material", "Sphere", "Plane", "Triangle", "Object", "Config", "Camera", "Scene",
+           "SceneHandle", "RtxError", "device_count", "pack_objects", "OBJECT_DTYPE",
+           "RTX_KERNEL_AUTO", "RTX_KERNEL_EXACT", "RTX_KERNEL_MIXED", "RTX_KERNEL_MIXED_VERIFY"]
+
+
+# ---------------------------------------------------------------------------------------------
+# math::Vector3 (math/vector.rs) -- a thin value type; only what the host API needs
+# ---------------------------------------------------------------------------------------------
+class Vector3:
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):                       # vector.rs:67-69
+        self.x, self.y, self.z = float(x), float(y), float(z)
+
+    @staticmethod
+    def zeros():
+        return Vector3(0.0, 0.0, 0.0)                               # vector.rs:81-83
+
+    @staticmethod
+    def ones():
+        return Vector3(1.0, 1.0, 1.0)                               # vector.rs:47-53
+
+    @staticmethod
+    def of(v):
+        """From<(A,B,C)> / From<[T;3]> (vector/into.rs:4-20)."""
+        if isinstance(v, Vector3):
+            return v
+        x, y, z = v
+        return Vector3(x, y, z)
+
+    def __iter__(self):
+        return iter((self.x, self.y, self.z))
+
+    def __eq__(self, o):
+        o = Vector3.of(o)
+        return self.x == o.x and self.y == o.y and self.z == o.z
+
+    def __neg__(self):
+        return Vector3(-self.x, -self.y, -self.z)
+
+    def __sub__(self, o):
+        o = Vector3.of(o)
+        return Vector3(self.x - o.x, self.y - o.y, self.z - o.z)
+
+    def __add__(self, o):
+        o = Vector3.of(o)
+        return Vector3(self.x + o.x, self.y + o.y, self.z + o.z)
+
+    def dot(self, o):                                               # vector.rs:85-87
+        return self.x * o.x + self.y * o.y + self.z * o.z
+
+    def __repr__(self):
+        return "Vector3(%r, %r, %r)" % (self.x, self.y, self.z)
+
+
+# ---------------------------------------------------------------------------------------------
+# object::{Material, Sphere, Plane, Triangle, Object} (object.rs, object/*.rs)
+# ---------------------------------------------------------------------------------------------
+class Material:                                                     # object.rs:78-86
+    def __init__(self, base_color, emission_color, roughness):      # Material::new, object.rs:92-94
+        self.base_color = Vector3.of(base_color)
+        self.emission_color = Vector3.of(emission_color)
+        self.roughness = float(roughness)
+
+    @staticmethod
+    def colored(color):                                             # object.rs:111-113
+        return Material(color, Vector3.zeros(), 1.0)
+
+    @staticmethod
+    def light(light_color):                                         # object.rs:130-132
+        return Material(Vector3.zeros(), light_color, 1.0)
+
+    @staticmethod
+    def mirror():                                                   # object.rs:133-135 (roughness 1.0 on the CPU path)
+        return Material(Vector3.ones(), Vector3.zeros(), 1.0)
+
+
+class Sphere:                                                       # object/sphere.rs:8-17
+    kind = RTX_SPHERE
+
+    def __init__(self, position, radius):
+        self.position = Vector3.of(position)
+        self.radius = float(radius)
+
+    def geom(self):
+        return [self.position.x, self.position.y, self.position.z, self.radius, 0, 0, 0, 0, 0]
+
+
+class Plane:                                                        # object/plane.rs:8-17
+    kind = RTX_PLANE
+
+    def __init__(self, position, normal):
+        self.position = Vector3.of(position)
+        self.normal = Vector3.of(normal)
+
+    def geom(self):
+        return [*self.position, *self.normal, 0, 0, 0]
+
+
+class Triangle:                                                     # object/triangle.rs:8-17
+    kind = RTX_TRIANGLE
+
+    def __init__(self, vertices):
+        self.vertices = [Vector3.of(v) for v in vertices]
+        if len(self.vertices) != 3:
+            raise ValueError("Triangle takes exactly three vertices")
+
+    def geom(self):
+        return [c for v in self.vertices for c in v]
+
+
+class Object:                                                       # object.rs:9-28
+    def __init__(self, shape, material):
+        if not hasattr(shape, "kind") or not hasattr(shape, "geom"):
+            # a user CustomShape (object.rs:53-76) has no device primitive; no fallback exists
+            raise RtxError(abi.RTX_ERR_UNSUPPORTED, "shape has no device primitive (only Sphere, Plane, Triangle)")
+        self.shape = shape
+        self.material = material
+
+
+def pack_objects(objects):
+    """Scene.objects -> contiguous RtxObject array (numpy, OBJECT_DTYPE) in scene order."""
+    arr = np.zeros(len(objects), dtype=OBJECT_DTYPE)
+    for i, o in enumerate(objects):
+        arr[i]["kind"] = o.shape.kind
+        arr[i]["geom"] = o.shape.geom()
+        arr[i]["base_color"] = tuple(o.material.base_color)
+        arr[i]["emission_color"] = tuple(o.material.emission_color)
+        arr[i]["roughness"] = o.material.roughness
+    return arr
+
+
+# ---------------------------------------------------------------------------------------------
+# Config (scene.rs:16-65) + the build's seed / kernel fields
+# ---------------------------------------------------------------------------------------------
+class Config:
+    def __init__(self, rays_per_pixel=16, max_bounces=10, focal_length=10.0, focal_offset=1e-4,
+                 non_focal_offset=1e-1, seed=42, kernel=RTX_KERNEL_AUTO):          # Default, scene.rs:55-65
+        self.rays_per_pixel = int(rays_per_pixel)
+        self.max_bounces = int(max_bounces)
+        self.focal_length = float(focal_length)
+        self.focal_offset = float(focal_offset)
+        self.non_focal_offset = float(non_focal_offset)
+        self.seed = int(seed)
+        self.kernel = int(kernel)
+
+    @staticmethod
+    def default():
+        return Config()
+
+    def _with(self, **kw):                                          # reassign!, scene.rs:29-37
+        c = Config(self.rays_per_pixel, self.max_bounces, self.focal_length, self.focal_offset,
+                   self.non_focal_offset, self.seed, self.kernel)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def with_rays_per_pixel(self, v):
+        return self._with(rays_per_pixel=int(v))                    # scene.rs:39-41
+
+    def with_max_bounces(self, v):
+        return self._with(max_bounces=int(v))                       # scene.rs:42-44
+
+    def with_focal_length(self, v):
+        return self._with(focal_length=float(v))                    # scene.rs:45-47
+
+    def with_focal_offset(self, v):
+        return self._with(focal_offset=float(v))                    # scene.rs:48-50
+
+    def with_non_focal_offset(self, v):
+        return self._with(non_focal_offset=float(v))                # scene.rs:51-53
+
+    def with_seed(self, v):
+        return self._with(seed=int(v))
+
+    def with_kernel(self, v):
+        return self._with(kernel=int(v))
+
+    def to_c(self):
+        return abi.RtxConfig(self.rays_per_pixel, self.max_bounces, self.focal_length, self.focal_offset,
+                             self.non_focal_offset, self.seed & 0xFFFFFFFFFFFFFFFF, self.kernel, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Camera (camera.rs:7-67); the matrices come from rtx_camera_new (host C++, reference op order)
+# ---------------------------------------------------------------------------------------------
+def _camera_c(position, direction, fov):
+    cam = abi.RtxCamera()
+    p = (C.c_double * 3)(*Vector3.of(position))
+    d = (C.c_double * 3)(*Vector3.of(direction))
+    abi.check(load_library().rtx_camera_new(p, d, float(fov), C.byref(cam)))
+    return cam
+
+
+def _mat_mul_vec(rows9, v):                                        # mat/mul.rs:42-50: rhs.dot(row)
+    return Vector3(v.x * rows9[0] + v.y * rows9[1] + v.z * rows9[2],
+                   v.x * rows9[3] + v.y * rows9[4] + v.z * rows9[5],
+                   v.x * rows9[6] + v.y * rows9[7] + v.z * rows9[8])
+
+
+class Camera:
+    def __init__(self, position, direction, fov):                   # camera.rs:19-28; fov in radians (camera.rs:8)
+        self.fov = float(fov)
+        self.position = Vector3.of(position)
+        self._direction = Vector3.of(direction)
+        c = _camera_c(self.position, self._direction, self.fov)
+        self._to_world = list(c.to_world_space)
+        self._to_cam = list(c.to_cam_space)
+
+    def get_direction(self):                                        # camera.rs:30-32
+        return self._direction
+
+    def set_direction(self, direction):                             # camera.rs:35-40
+        # as the reference: the matrices are derived from the OLD direction, then the new one is stored
+        c = _camera_c(self.position, self._direction, self.fov)
+        self._to_world = list(c.to_world_space)
+        self._to_cam = list(c.to_cam_space)
+        self._direction = Vector3.of(direction)
+
+    def to_cam_space(self, vec):                                    # camera.rs:51-53
+        return _mat_mul_vec(self._to_cam, Vector3.of(vec) - self.position)
+
+    def to_world_space(self, vec):                                  # camera.rs:55-57
+        return _mat_mul_vec(self._to_world, Vector3.of(vec)) + self.position
+
+    def rotate_to_world_space(self, vec):                           # camera.rs:65-67
+        return _mat_mul_vec(self._to_world, Vector3.of(vec))
+
+    def to_c(self):
+        cam = abi.RtxCamera()
+        cam.fov = self.fov
+        cam.position[:] = list(self.position)
+        cam.direction[:] = list(self._direction)
+        cam.to_world_space[:] = self._to_world
+        cam.to_cam_space[:] = self._to_cam
+        return cam
+
+
+# ---------------------------------------------------------------------------------------------
+# Scene (scene.rs:78-178)
+# ---------------------------------------------------------------------------------------------
+def _scene_c(config, camera, packed):
+    s = abi.RtxScene()
+    s.config = config.to_c()
+    s.camera = camera.to_c()
+    s.n_objects = len(packed)
+    s.objects = packed.ctypes.data if len(packed) else None
+    return s
+
+
+def device_count():
+    return int(load_library().rtx_device_count())
+
+
+class Scene:
+    def __init__(self, config=None, camera=None):                   # Scene::new scene.rs:112-118 / Default :86-94
+        self.config = config if config is not None else Config()
+        self.camera = camera if camera is not None else Camera((0, 0, 0), (1, 0, 0), 90.0)
+        self.objects = []
+        self._packed = None            # optional pre-packed RtxObject array (bulk scenes)
+
+    @staticmethod
+    def from_packed(config, camera, packed):
+        """Bulk constructor: `packed` is an OBJECT_DTYPE array already in Scene.objects order."""
+        s = Scene(config, camera)
+        s._packed = np.ascontiguousarray(packed, dtype=OBJECT_DTYPE)
+        return s
+
+    def add_object(self, obj):                                      # scene.rs:126-128
+        if self._packed is not None:
+            raise ValueError("scene was built from a packed array")
+        self.objects.append(obj)
+
+    def packed(self):
+        return self._packed if self._packed is not None else pack_objects(self.objects)
+
+    def render(self, width, height):                                # scene.rs:144-170
+        """img[y][x] -> float64 array (height, width, 3), unclamped, row 0 = the reference's row 0."""
+        width, height = int(width), int(height)
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        packed = self.packed()
+        sc = _scene_c(self.config, self.camera, packed)
+        abi.check(load_library().rtx_render(C.byref(sc), width, height, out.ctypes.data))
+        return out
+
+    def render_to_image(self, width, height):                       # scene.rs:172-178
+        """ImageBuffer<Rgb<u8>> as uint8 array (height, width, 3): x256, saturating, flipped vertically."""
+        width, height = int(width), int(height)
+        out = np.zeros((height, width, 3), dtype=np.uint8)
+        packed = self.packed()
+        sc = _scene_c(self.config, self.camera, packed)
+        abi.check(load_library().rtx_render_to_image(C.byref(sc), width, height, out.ctypes.data))
+        return out
+
+    def upload(self, device=0):
+        return SceneHandle(self, device)
+
+
+class SceneHandle:
+    """Split form of the C ABI: scene resident on one device, rows rendered into device buffers."""
+
+    def __init__(self, scene, device=0):
+        self._lib = load_library()
+        self.device = int(device)
+        self._h = C.c_void_p()
+        packed = scene.packed()
+        sc = _scene_c(scene.config, scene.camera, packed)
+        abi.check(self._lib.rtx_scene_upload(C.byref(sc), self.device, C.byref(self._h)))
+
+    def set_config(self, config):
+        c = config.to_c()
+        abi.check(self._lib.rtx_scene_set_config(self._h, C.byref(c)))
+
+    def render_rows(self, width, height, row_begin, row_stride, n_rows, d_out_ptr, stream=None, want_stats=True):
+        """d_out_ptr: device address of n_rows*width*3 doubles (e.g. a torch tensor's data_ptr())."""
+        stats = abi.RtxStats()
+        abi.check(self._lib.rtx_render_rows(self._h, int(width), int(height), int(row_begin), int(row_stride),
+                                            int(n_rows), C.c_void_p(int(d_out_ptr)),
+                                            C.c_void_p(int(stream)) if stream else None,
+                                            C.byref(stats) if want_stats else None))
+        return stats if want_stats else None
+
+    def close(self):
+        if self._h:
+            self._lib.rtx_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def debug_math(op, a, b=None):
+    """Device evaluation of one f64 op per element (tests only): 0 a/b, 1 sqrt, 2 sin, 3 cos."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)
+    out = np.zeros_like(a)
+    abi.check(load_library().rtx_debug_math(int(op), a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
+    return out

@@ -1,0 +1,95 @@
+"""ctypes view of include/rtx_hip.h (the C ABI of librtx_hip.so).
+
+The library is the product: if it is missing or cannot be loaded this module raises --
+there is no Python/NumPy/CPU fallback for the render path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtx_hip.so")
+
+RTX_SPHERE, RTX_PLANE, RTX_TRIANGLE = 0, 1, 2
+RTX_KERNEL_AUTO, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY = 0, 1, 2, 3
+RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
+
+# RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)
+OBJECT_DTYPE = np.dtype([
+    ("kind", "<u4"), ("reserved", "<u4"), ("geom", "<f8", (9,)),
+    ("base_color", "<f8", (3,)), ("emission_color", "<f8", (3,)), ("roughness", "<f8"),
+])
+assert OBJECT_DTYPE.itemsize == 136
+
+
+class RtxConfig(C.Structure):
+    _fields_ = [("rays_per_pixel", C.c_uint64), ("max_bounces", C.c_uint64),
+                ("focal_length", C.c_double), ("focal_offset", C.c_double), ("non_focal_offset", C.c_double),
+                ("seed", C.c_uint64), ("kernel", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class RtxCamera(C.Structure):
+    _fields_ = [("fov", C.c_double), ("position", C.c_double * 3), ("direction", C.c_double * 3),
+                ("to_cam_space", C.c_double * 9), ("to_world_space", C.c_double * 9)]
+
+
+class RtxScene(C.Structure):
+    _fields_ = [("config", RtxConfig), ("camera", RtxCamera), ("n_objects", C.c_uint64), ("objects", C.c_void_p)]
+
+
+class RtxStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("segments", C.c_uint64), ("exact_tests", C.c_uint64),
+                ("filter_tests", C.c_uint64), ("trace_ms", C.c_double), ("resolve_ms", C.c_double),
+                ("filter_mismatches", C.c_uint64), ("trace_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/rtx_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("rtx_version", C.c_int32, []),
+    ("rtx_last_error", C.c_char_p, []),
+    ("rtx_device_count", C.c_int32, []),
+    ("rtx_camera_new", C.c_int32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(RtxCamera)]),
+    ("rtx_render", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("rtx_render_to_image", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("rtx_scene_upload", C.c_int32, [C.POINTER(RtxScene), C.c_int32, C.POINTER(C.c_void_p)]),
+    ("rtx_scene_free", C.c_int32, [C.c_void_p]),
+    ("rtx_scene_set_config", C.c_int32, [C.c_void_p, C.POINTER(RtxConfig)]),
+    ("rtx_render_rows", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_void_p, C.c_void_p, C.POINTER(RtxStats)]),
+    ("rtx_quantize_image_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("rtx_debug_math", C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+]
+
+
+class RtxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("librtx_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen librtx_hip.so and bind every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "librtx_hip.so is not built (%s). Build it with `python rust-raytracing_amd/build.py` "
+            "(hipcc, gfx950). There is no CPU fallback for the render path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load_library().rtx_last_error()
+        raise RtxError(status, msg.decode("utf-8", "replace") if msg else "")

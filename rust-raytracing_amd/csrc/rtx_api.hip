@@ -1,0 +1,492 @@
+// rtx_api.hip -- host side of librtx_hip.so: the extern "C" entry points of include/rtx_hip.h.
+// Scene packing (Scene.objects -> per-type device arrays with scene-order ids), the
+// ray-independent precompute, scratch management, kernel launches, timing.
+// There is no CPU fallback in this file: every render path ends in a gfx950 kernel launch.
+#include "../../include/rtx_hip.h"
+#include "rtx_launch.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtx;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(RtxStatus st, const std::string &msg)
+{
+    g_last_error = msg;
+    return (int32_t)st;
+}
+
+#define RTX_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+    } while (0)
+
+bool device_is_gfx950(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+int usable_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+size_t scratch_cap_bytes()
+{
+    const char *e = std::getenv("RTX_HIP_SCRATCH_MB");
+    size_t mb = 8192;
+    if (e && *e) { long v = std::strtol(e, nullptr, 10); if (v > 0) mb = (size_t)v; }
+    return mb << 20;
+}
+
+}  // namespace
+
+struct RtxSceneHandle_ {
+    int device = 0;
+    int n_cus = 0;
+    RtxConfig cfg{};
+    RtxCamera cam{};
+    SceneView sv{};
+    std::vector<void *> scene_allocs;
+    // scratch, grown on demand
+    double *samples = nullptr;  size_t samples_bytes = 0;
+    double *acc = nullptr;      size_t acc_bytes = 0;
+    double *tables = nullptr;   size_t tables_doubles = 0;
+    double *h_tables = nullptr; size_t h_tables_doubles = 0;
+    double *state = nullptr;    size_t state_bytes = 0;
+    Counters *counters = nullptr;
+    unsigned long long *work_counter = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    // what the trig tables currently hold
+    uint32_t t_w = 0, t_h = 0, t_rb = 0, t_rs = 0, t_nr = 0;
+    double t_fov = 0.0;
+    bool t_valid = false;
+};
+
+namespace {
+
+template <class T>
+int32_t upload_vec(RtxSceneHandle_ *h, const std::vector<T> &v, const T **out)
+{
+    *out = nullptr;
+    if (v.empty()) return RTX_OK;
+    void *d = nullptr;
+    RTX_HIP_CHECK(hipMalloc(&d, v.size() * sizeof(T)));
+    h->scene_allocs.push_back(d);
+    RTX_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return RTX_OK;
+}
+
+void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
+{
+    h->cfg = cfg;
+    h->sv.rays_per_pixel = cfg.rays_per_pixel;
+    h->sv.max_bounces = cfg.max_bounces;
+    h->sv.focal_length = cfg.focal_length;
+    h->sv.focal_offset = cfg.focal_offset;
+    h->sv.non_focal_offset = cfg.non_focal_offset;
+    h->sv.seed = cfg.seed;
+}
+
+int32_t check_config(const RtxConfig &cfg)
+{
+    if (cfg.kernel > RTX_KERNEL_MIXED_VERIFY) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
+    if (cfg.max_bounces == UINT64_MAX)       // max_bounces + 1 overflows in the reference (scene.rs:227)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.max_bounces + 1 overflows");
+    if (cfg.rays_per_pixel > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.rays_per_pixel exceeds 2^32-1");
+    return RTX_OK;
+}
+
+int32_t grow(void **p, size_t *have, size_t want)
+{
+    if (*have >= want && *p) return RTX_OK;
+    if (*p) { RTX_HIP_CHECK(hipFree(*p)); *p = nullptr; *have = 0; }
+    if (want == 0) return RTX_OK;
+    RTX_HIP_CHECK(hipMalloc(p, want));
+    *have = want;
+    return RTX_OK;
+}
+
+void free_handle(RtxSceneHandle_ *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void *p : h->scene_allocs) (void)hipFree(p);
+    if (h->samples) (void)hipFree(h->samples);
+    if (h->acc) (void)hipFree(h->acc);
+    if (h->tables) (void)hipFree(h->tables);
+    if (h->h_tables) (void)hipHostFree(h->h_tables);
+    if (h->state) (void)hipFree(h->state);
+    if (h->counters) (void)hipFree(h->counters);
+    if (h->work_counter) (void)hipFree(h->work_counter);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    delete h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rtx_version(void) { return RTX_HIP_VERSION; }
+
+const char *rtx_last_error(void) { return g_last_error.c_str(); }
+
+int32_t rtx_device_count(void) { return usable_device_count(); }
+
+int32_t rtx_camera_new(const double position[3], const double direction[3], double fov, RtxCamera *out)
+{
+    if (!position || !direction || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_camera_new: null argument");
+    // camera.rs:42-49 derive_to_world_space_mat
+    V3 cam_forward = vnorm(mk(direction[0], direction[1], direction[2]));
+    V3 cam_right = cross(cam_forward, mk(0., 0., -1.));
+    V3 cam_up = cross(cam_forward, cam_right);
+    // Mat3x3::new(right, up, forward).transpose()  (specific_math.rs:16-21)
+    V3 rx = mk(cam_right.x, cam_up.x, cam_forward.x);
+    V3 ry = mk(cam_right.y, cam_up.y, cam_forward.y);
+    V3 rz = mk(cam_right.z, cam_up.z, cam_forward.z);
+    // inverse = adjugate / determinant  (specific_math.rs:10-14, :23-71; mat/div.rs:10-20)
+    double a = rx.x, b = rx.y, c = rx.z, d = ry.x, e = ry.y, f = ry.z, g = rz.x, hh = rz.y, i = rz.z;
+    double sum1 = a * e * i, sum2 = b * f * g, sum3 = c * d * hh;
+    double sub1 = g * e * c, sub2 = hh * f * a, sub3 = i * d * b;
+    double det = (sum1 + sum2 + sum3) - (sub1 + sub2 + sub3);
+    V3 ax = mk(e * i - f * hh, c * hh - b * i, b * f - c * e);
+    V3 ay = mk(f * g - d * i, a * i - c * g, c * d - a * f);
+    V3 az = mk(d * hh - e * g, b * g - a * hh, a * e - b * d);
+    V3 ix = vdivs(ax, det), iy = vdivs(ay, det), iz = vdivs(az, det);
+    out->fov = fov;
+    for (int k = 0; k < 3; ++k) { out->position[k] = position[k]; out->direction[k] = direction[k]; }
+    const V3 w[3] = { rx, ry, rz }, cinv[3] = { ix, iy, iz };
+    for (int r = 0; r < 3; ++r) {
+        out->to_world_space[3 * r] = w[r].x; out->to_world_space[3 * r + 1] = w[r].y; out->to_world_space[3 * r + 2] = w[r].z;
+        out->to_cam_space[3 * r] = cinv[r].x; out->to_cam_space[3 * r + 1] = cinv[r].y; out->to_cam_space[3 * r + 2] = cinv[r].z;
+    }
+    return RTX_OK;
+}
+
+int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *out)
+{
+    if (!scene || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: null argument");
+    *out = nullptr;
+    if (scene->n_objects && !scene->objects) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: objects is null");
+    if (scene->n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: too many objects");
+    if (int32_t rc = check_config(scene->config)) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        (void)hipGetLastError();
+        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; librtx_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: bad device index");
+    if (!device_is_gfx950(device)) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library targets gfx950 only");
+    RTX_HIP_CHECK(hipSetDevice(device));
+
+    RtxSceneHandle_ *h = new RtxSceneHandle_();
+    h->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, "hipGetDeviceProperties failed"); }
+    h->n_cus = prop.multiProcessorCount;
+    h->cam = scene->camera;
+    apply_config(h, scene->config);
+
+    const uint64_t n = scene->n_objects;
+    std::vector<SphereX> spheres; std::vector<uint32_t> sphere_id;
+    std::vector<PlaneX> planes; std::vector<TriX> tris;
+    std::vector<MaterialX> mats(n);
+    double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint64_t k = 0; k < n; ++k) {
+        const RtxObject &o = scene->objects[k];
+        mats[k].base_color = mk(o.base_color[0], o.base_color[1], o.base_color[2]);
+        mats[k].emission_color = mk(o.emission_color[0], o.emission_color[1], o.emission_color[2]);
+        mats[k].roughness = o.roughness;
+        switch (o.kind) {
+            case RTX_SPHERE:
+                spheres.push_back(make_sphere(o.geom));
+                sphere_id.push_back((uint32_t)k);
+                for (int c = 0; c < 3; ++c) {
+                    if (std::isfinite(o.geom[c])) { lo[c] = std::fmin(lo[c], o.geom[c]); hi[c] = std::fmax(hi[c], o.geom[c]); }
+                }
+                break;
+            case RTX_PLANE: planes.push_back(make_plane(o.geom, (uint32_t)k)); break;
+            case RTX_TRIANGLE: tris.push_back(make_triangle(o.geom, (uint32_t)k)); break;
+            default:
+                free_handle(h);
+                return fail(RTX_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": kind " + std::to_string(o.kind) +
+                                                     " has no device primitive (user CustomShape impls cannot run on the GPU)");
+        }
+    }
+    // f32 filter records, relative to the centre of the spheres' bounding box
+    std::vector<float4> sph32(spheres.size());
+    double centre[3] = { 0, 0, 0 };
+    for (int c = 0; c < 3; ++c) if (lo[c] <= hi[c]) centre[c] = 0.5 * (lo[c] + hi[c]);
+    double cmax = 0.0;
+    for (size_t k = 0; k < spheres.size(); ++k) {
+        const RtxObject &o = scene->objects[sphere_id[k]];
+        double cx = o.geom[0] - centre[0], cy = o.geom[1] - centre[1], cz = o.geom[2] - centre[2];
+        double cc = cx * cx + cy * cy + cz * cz;
+        double reach = std::sqrt(cc) + std::fabs(o.geom[3]);
+        if (!(reach <= cmax)) cmax = reach;                   // NaN/inf propagate: the filter then passes everything
+        sph32[k] = make_float4((float)cx, (float)cy, (float)cz, (float)(cc - spheres[k].rr));
+    }
+    h->sv.n_objects = (uint32_t)n;
+    h->sv.n_spheres = (uint32_t)spheres.size();
+    h->sv.n_planes = (uint32_t)planes.size();
+    h->sv.n_tris = (uint32_t)tris.size();
+    for (int c = 0; c < 3; ++c) h->sv.sphere_center[c] = centre[c];
+    h->sv.sphere_cmax = cmax;
+    h->sv.cam_pos = mk(h->cam.position[0], h->cam.position[1], h->cam.position[2]);
+    h->sv.to_world_x = mk(h->cam.to_world_space[0], h->cam.to_world_space[1], h->cam.to_world_space[2]);
+    h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
+    h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
+
+    int32_t rc = RTX_OK;
+    if (!rc) rc = upload_vec(h, spheres, &h->sv.spheres);
+    if (!rc) rc = upload_vec(h, sphere_id, &h->sv.sphere_id);
+    if (!rc) rc = upload_vec(h, planes, &h->sv.planes);
+    if (!rc) rc = upload_vec(h, tris, &h->sv.tris);
+    if (!rc) rc = upload_vec(h, mats, &h->sv.materials);
+    if (!rc) rc = upload_vec(h, sph32, &h->sv.sphere_f32);
+    if (rc) { free_handle(h); return rc; }
+
+    hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
+    if (e != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, std::string("scene scratch: ") + hipGetErrorString(e)); }
+    *out = h;
+    return RTX_OK;
+}
+
+int32_t rtx_scene_free(RtxSceneHandle scene)
+{
+    free_handle(scene);
+    return RTX_OK;
+}
+
+int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config)
+{
+    if (!scene || !config) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_set_config: null argument");
+    if (int32_t rc = check_config(*config)) return rc;
+    apply_config(scene, *config);
+    return RTX_OK;
+}
+
+int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_stride,
+                        uint32_t n_rows, double *d_out_rgb, void *stream_, RtxStats *stats)
+{
+    if (!h) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: null scene");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n_rows == 0 || width == 0) return RTX_OK;
+    if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: null output");
+    if (row_stride == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: row_stride == 0");
+    if ((uint64_t)row_begin + (uint64_t)(n_rows - 1) * row_stride >= height)
+        return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: rows exceed the image height");
+    if ((uint64_t)n_rows * width > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: more than 2^32 pixels per call");
+    RTX_HIP_CHECK(hipSetDevice(h->device));
+
+    const uint32_t npix = n_rows * width;
+    const uint64_t spp = h->cfg.rays_per_pixel;
+    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? RTX_KERNEL_MIXED : h->cfg.kernel;
+
+    // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row
+    const size_t tdbl = 2 * (size_t)width + 2 * (size_t)n_rows;
+    const bool t_same = h->t_valid && h->t_w == width && h->t_h == height && h->t_rb == row_begin &&
+                        h->t_rs == row_stride && h->t_nr == n_rows && h->t_fov == h->cam.fov;
+    if (!t_same) {
+        RTX_HIP_CHECK(hipStreamSynchronize(stream));        // an earlier enqueued copy may still read h_tables
+        if (h->h_tables_doubles < tdbl) {
+            if (h->h_tables) RTX_HIP_CHECK(hipHostFree(h->h_tables));
+            h->h_tables = nullptr; h->h_tables_doubles = 0;
+            RTX_HIP_CHECK(hipHostMalloc((void **)&h->h_tables, tdbl * sizeof(double), hipHostMallocDefault));
+            h->h_tables_doubles = tdbl;
+        }
+        {
+            size_t have = h->tables_doubles * sizeof(double);
+            if (int32_t rc = grow((void **)&h->tables, &have, tdbl * sizeof(double))) return rc;
+            h->tables_doubles = have / sizeof(double);
+        }
+        const double fov = h->cam.fov;
+        const double vertical_fov = (double)height / (double)width * fov;             // scene.rs:145
+        double *sx = h->h_tables, *cx = sx + width, *sy = cx + width, *cy = sy + n_rows;
+        for (uint32_t x = 0; x < width; ++x) {
+            double u = (double)x / (double)width;                                       // scene.rs:157
+            double angle_x = fov * (u - 0.5);                                           // scene.rs:214
+            sx[x] = std::sin(angle_x); cx[x] = std::cos(angle_x);
+        }
+        for (uint32_t k = 0; k < n_rows; ++k) {
+            double v = (double)(row_begin + k * row_stride) / (double)height;           // scene.rs:153
+            double angle_y = vertical_fov * (v - 0.5);                                  // scene.rs:215
+            sy[k] = std::sin(angle_y); cy[k] = std::cos(angle_y);
+        }
+        RTX_HIP_CHECK(hipMemcpyAsync(h->tables, h->h_tables, tdbl * sizeof(double), hipMemcpyHostToDevice, stream));
+        h->t_w = width; h->t_h = height; h->t_rb = row_begin; h->t_rs = row_stride; h->t_nr = n_rows;
+        h->t_fov = fov; h->t_valid = true;
+    }
+
+    // ---- scratch: one RGB per ray of a sample batch, the running per-pixel sum, the SoA ray state
+    uint64_t batch = spp;
+    {
+        const uint64_t per_sample = (uint64_t)npix * 3 * sizeof(double);
+        const uint64_t fit = scratch_cap_bytes() / per_sample;
+        if (batch > fit) batch = fit ? fit : 1;
+    }
+    if (spp > 0) {
+        if (int32_t rc = grow((void **)&h->samples, &h->samples_bytes, (size_t)(batch * npix * 3 * sizeof(double)))) return rc;
+    }
+    if (batch < spp) {
+        if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
+    }
+    if (kernel != RTX_KERNEL_EXACT) {
+        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
+    }
+
+    RowsView rv{};
+    rv.width = width; rv.height = height;
+    rv.row_begin = row_begin; rv.row_stride = row_stride; rv.n_rows = n_rows;
+    rv.npix = npix;
+    rv.sin_x = h->tables; rv.cos_x = h->tables + width;
+    rv.sin_y = h->tables + 2 * (size_t)width; rv.cos_y = rv.sin_y + n_rows;
+
+    RTX_HIP_CHECK(hipMemsetAsync(h->counters, 0, sizeof(Counters) * kCounterShards, stream));
+    float trace_ms = 0.f, resolve_ms = 0.f;
+    uint32_t launches = 0;
+
+    if (spp == 0) {
+        // avg() of an empty iterator: 0/0 = NaN per component (scene.rs:253-259)
+        RTX_HIP_CHECK(launch_resolve(nullptr, nullptr, d_out_rgb, npix, 0, 0, true, true, stream));
+    }
+    for (uint64_t s0 = 0; s0 < spp; s0 += batch) {
+        const uint64_t ns = (spp - s0 < batch) ? spp - s0 : batch;
+        rv.sample_begin = (uint32_t)s0;
+        rv.n_samples = (uint32_t)ns;
+        rv.n_rays = (uint64_t)npix * ns;
+        if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
+        if (kernel == RTX_KERNEL_EXACT) {
+            RTX_HIP_CHECK(launch_trace_exact(h->sv, rv, h->samples, h->counters, stream));
+        } else {
+            RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
+            RTX_HIP_CHECK(launch_trace_mixed(h->sv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,
+                                             kernel == RTX_KERNEL_MIXED_VERIFY, stream));
+        }
+        ++launches;
+        if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[1], stream));
+        RTX_HIP_CHECK(launch_resolve(h->samples, h->acc, d_out_rgb, npix, (uint32_t)ns, spp, s0 == 0, s0 + ns == spp, stream));
+        if (stats) {
+            RTX_HIP_CHECK(hipEventRecord(h->ev[2], stream));
+            RTX_HIP_CHECK(hipEventSynchronize(h->ev[2]));
+            float a = 0.f, b = 0.f;
+            RTX_HIP_CHECK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+            RTX_HIP_CHECK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+            trace_ms += a; resolve_ms += b;
+        }
+    }
+    if (stats) {
+        RTX_HIP_CHECK(hipStreamSynchronize(stream));
+        Counters host[kCounterShards];
+        RTX_HIP_CHECK(hipMemcpy(host, h->counters, sizeof host, hipMemcpyDeviceToHost));
+        for (int k = 0; k < kCounterShards; ++k) {
+            stats->segments += host[k].segments;
+            stats->exact_tests += host[k].exact_tests;
+            stats->filter_tests += host[k].filter_tests;
+        }
+        stats->filter_mismatches = host[0].pad_;
+        if (host[1].pad_ != 0)
+            return fail(RTX_ERR_HIP, "trace kernel hit its round bound (internal error): " + std::to_string(host[1].pad_) +
+                                         " workgroup(s) left early");
+        stats->primary_rays = (uint64_t)npix * spp;
+        stats->trace_ms = trace_ms;
+        stats->resolve_ms = resolve_ms;
+        stats->trace_launches = launches;
+    }
+    return RTX_OK;
+}
+
+int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t height, uint8_t *d_rgb8, int32_t device,
+                                  void *stream)
+{
+    if ((uint64_t)width * height == 0) return RTX_OK;
+    if (!d_rgb || !d_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_quantize_image_device: null argument");
+    RTX_HIP_CHECK(hipSetDevice(device));
+    RTX_HIP_CHECK(launch_quantize(d_rgb, d_rgb8, width, height, static_cast<hipStream_t>(stream)));
+    return RTX_OK;
+}
+
+static int32_t render_common(const RtxScene *scene, uint32_t width, uint32_t height, double *out_rgb, uint8_t *out_rgb8)
+{
+    if (!scene) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null scene");
+    const uint64_t npix = (uint64_t)width * height;
+    if (npix == 0) return RTX_OK;                     // vec![vec![..; 0]; h] renders nothing (scene.rs:146)
+    if (!out_rgb && !out_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null output");
+    RtxSceneHandle h = nullptr;
+    if (int32_t rc = rtx_scene_upload(scene, 0, &h)) return rc;
+    double *d_out = nullptr;
+    uint8_t *d_q = nullptr;
+    int32_t rc = RTX_OK;
+    hipError_t e = hipMalloc((void **)&d_out, npix * 3 * sizeof(double));
+    if (e == hipSuccess && out_rgb8) e = hipMalloc((void **)&d_q, npix * 3);
+    if (e != hipSuccess) rc = fail(RTX_ERR_OUT_OF_MEMORY, std::string("rtx_render: ") + hipGetErrorString(e));
+    RtxStats st;
+    const bool dbg = std::getenv("RTX_HIP_DEBUG") != nullptr;
+    if (!rc) rc = rtx_render_rows(h, width, height, 0, 1, height, d_out, nullptr, &st);
+    if (!rc && dbg)
+        std::fprintf(stderr, "[rtx_hip] rays %llu segments %llu exact %llu filter %llu mismatches %llu trace %.3f ms resolve %.3f ms\n",
+                     (unsigned long long)st.primary_rays, (unsigned long long)st.segments, (unsigned long long)st.exact_tests,
+                     (unsigned long long)st.filter_tests, (unsigned long long)st.filter_mismatches, st.trace_ms, st.resolve_ms);
+    if (!rc && out_rgb8) rc = rtx_quantize_image_device(d_out, width, height, d_q, 0, nullptr);
+    if (!rc) {
+        e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && out_rgb) e = hipMemcpy(out_rgb, d_out, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_rgb8) e = hipMemcpy(out_rgb8, d_q, npix * 3, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RTX_ERR_HIP, std::string("rtx_render: ") + hipGetErrorString(e));
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (d_q) (void)hipFree(d_q);
+    rtx_scene_free(h);
+    return rc;
+}
+
+int32_t rtx_render(const RtxScene *scene, uint32_t width, uint32_t height, double *out_rgb)
+{
+    return render_common(scene, width, height, out_rgb, nullptr);
+}
+
+int32_t rtx_render_to_image(const RtxScene *scene, uint32_t width, uint32_t height, uint8_t *out_rgb8)
+{
+    return render_common(scene, width, height, nullptr, out_rgb8);
+}
+
+int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n)
+{
+    if (n == 0) return RTX_OK;
+    if (!a || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_math: null argument");
+    if (usable_device_count() == 0) return fail(RTX_ERR_NO_DEVICE, "no gfx950 device");
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    RTX_HIP_CHECK(hipSetDevice(0));
+    RTX_HIP_CHECK(hipMalloc((void **)&da, n * sizeof(double)));
+    RTX_HIP_CHECK(hipMalloc((void **)&db, n * sizeof(double)));
+    RTX_HIP_CHECK(hipMalloc((void **)&dout, n * sizeof(double)));
+    RTX_HIP_CHECK(hipMemcpy(da, a, n * sizeof(double), hipMemcpyHostToDevice));
+    RTX_HIP_CHECK(hipMemcpy(db, b ? b : a, n * sizeof(double), hipMemcpyHostToDevice));
+    RTX_HIP_CHECK(launch_debug_math(op, da, db, dout, n, nullptr));
+    RTX_HIP_CHECK(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return RTX_OK;
+}
+
+}  // extern "C"

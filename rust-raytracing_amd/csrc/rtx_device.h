@@ -1,0 +1,167 @@
+// rtx_device.h -- kernel-side views of an uploaded scene and the per-ray path logic shared by the
+// EXACT and MIXED trace kernels (primary-ray generation, shading, bounce direction).
+#pragma once
+
+#include "rtx_scene.h"
+
+namespace rtx {
+
+// Everything a trace kernel needs, passed by value as a kernel argument.
+struct SceneView {
+    // Config (scene.rs:16-28) + seed
+    uint64_t rays_per_pixel;
+    uint64_t max_bounces;
+    double   focal_length, focal_offset, non_focal_offset;
+    uint64_t seed;
+    // Camera (camera.rs:7-15): what render() reads
+    V3 cam_pos;
+    V3 to_world_x, to_world_y, to_world_z;     // rows of to_world_space (mat.rs:11-18)
+    // shapes, segregated by type; ids give the index in Scene.objects (tie-break, scene.rs:250)
+    uint32_t n_objects, n_spheres, n_planes, n_tris;
+    const SphereX  *spheres;
+    const uint32_t *sphere_id;
+    const PlaneX   *planes;
+    const TriX     *tris;
+    const MaterialX *materials;                // by scene index
+    // f32 filter records for the MIXED kernel
+    const float4   *sphere_f32;                // {c - centre (xyz), |c - centre|^2 - r*r}
+    double          sphere_center[3];          // centre of the spheres' bounding box
+    double          sphere_cmax;               // max over spheres of |c - centre| + r
+};
+
+// Which pixels/samples one launch covers.
+struct RowsView {
+    uint32_t width, height;
+    uint32_t row_begin, row_stride, n_rows;
+    uint32_t npix;                 // n_rows * width  (local pixels)
+    uint32_t sample_begin;         // first sample index of this batch
+    uint32_t n_samples;            // samples in this batch
+    uint64_t n_rays;               // npix * n_samples
+    // host-libm trig tables (scene.rs:214-220): sin/cos(fov*(x/w-0.5)) per column,
+    // sin/cos(vfov*(y/h-0.5)) per LOCAL row
+    const double *sin_x, *cos_x, *sin_y, *cos_y;
+};
+
+// Sharded counters (one slot per wave-id hash) summed on the host.
+struct Counters {
+    unsigned long long segments;
+    unsigned long long exact_tests;
+    unsigned long long filter_tests;
+    unsigned long long pad_;
+};
+constexpr int kCounterShards = 64;
+
+struct RayState {                  // raytracing/ray.rs:4-21 + RNG cursor
+    V3 pos, dir, result, light;
+    uint64_t key;
+    uint32_t draw;
+    uint32_t bounce;
+};
+
+struct Hit {
+    double   t;
+    uint32_t id;                   // scene index of the winner; 0xFFFFFFFF = none
+    uint32_t kind;                 // RTX_SPHERE/PLANE/TRIANGLE
+    uint32_t local;                // index inside its type array
+};
+
+__device__ __forceinline__ void hit_init(Hit &h) { h.t = 0.0; h.id = 0xFFFFFFFFu; h.kind = 0; h.local = 0; }
+
+// closest_object's filter + min_by (scene.rs:249-250): keep is_normal && positive; the FIRST
+// minimal element in Scene.objects order wins -> lexicographic (t, id).
+__device__ __forceinline__ void hit_consider(Hit &h, double t, uint32_t id, uint32_t kind, uint32_t local)
+{
+    if (!is_normal_positive(t)) return;
+    if (h.id == 0xFFFFFFFFu || t < h.t || (t == h.t && id < h.id)) { h.t = t; h.id = id; h.kind = kind; h.local = local; }
+}
+
+// map a ray index of the launch to (local pixel, sample), pixel-fastest so that a wave's 64 rays
+// are 64 neighbouring pixels of one sample (coalesced sample-plane writes).
+__device__ __forceinline__ void ray_index_to_pixel(const RowsView &rv, uint64_t i, uint32_t &pl, uint32_t &s_local)
+{
+    s_local = (uint32_t)(i / rv.npix);
+    pl = (uint32_t)(i - (uint64_t)s_local * rv.npix);
+}
+
+// render_pixel's per-sample prologue (scene.rs:196-207) + get_ray_dir (scene.rs:213-222).
+__device__ __forceinline__ void gen_primary(const SceneView &sv, const RowsView &rv, uint32_t pl, uint32_t sample,
+                                            RayState &r)
+{
+    uint32_t k = pl / rv.width;                    // local row
+    uint32_t x = pl - k * rv.width;
+    uint32_t y = rv.row_begin + k * rv.row_stride;
+    uint64_t pix = (uint64_t)y * rv.width + x;     // index in the FULL image keys the RNG
+    // scene.rs:216-221 with the host-computed trig values
+    V3 cam_space_dir = mk(rv.sin_x[x], rv.sin_y[k], rv.cos_x[x] * rv.cos_y[k]);
+    V3 ray_dir = mk(dot(cam_space_dir, sv.to_world_x), dot(cam_space_dir, sv.to_world_y),
+                    dot(cam_space_dir, sv.to_world_z));                  // mat/mul.rs:42-50
+    r.key = rng_key(sv.seed, pix, sample);
+    V3 rnd1;                                                             // vector.rs:29-35: x, y, z in order
+    rnd1.x = rng_u01(r.key, 0); rnd1.y = rng_u01(r.key, 1); rnd1.z = rng_u01(r.key, 2);
+    V3 ray_position = vadd(sv.cam_pos, vmuls(rnd1, sv.non_focal_offset));      // scene.rs:202
+    V3 focal_point = vadd(sv.cam_pos, vmuls(ray_dir, sv.focal_length));        // scene.rs:203
+    V3 rnd2;
+    rnd2.x = rng_u01(r.key, 3); rnd2.y = rng_u01(r.key, 4); rnd2.z = rng_u01(r.key, 5);
+    V3 target_point = vadd(focal_point, vmuls(rnd2, sv.focal_offset));         // scene.rs:204
+    V3 ray_direction = vsub(target_point, ray_position);                       // scene.rs:205
+    r.pos = ray_position;
+    r.dir = vnorm(ray_direction);                                              // scene.rs:207
+    r.result = mk(0.0, 0.0, 0.0);                                              // ray.rs:18
+    r.light = mk(1.0, 1.0, 1.0);                                               // ray.rs:19
+    r.draw = 6;
+    r.bounce = 0;
+}
+
+// Vector3::random_direction (vector.rs:36-45)
+__device__ __forceinline__ V3 random_direction(double u_z, double u_theta)
+{
+    double z = u_z * 2.0 - 1.0;
+    double theta = u_theta * 2.0 * 3.14159265358979323846;
+    double r = sqrt(1.0 - z * z);
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    return vnorm(mk(r * cs, r * sn, z));
+}
+
+// random_bounce_dir (scene.rs:279-292)
+__device__ __forceinline__ V3 random_bounce_dir(V3 ray_dir, V3 surface_normal, double surface_roughness,
+                                                double u_z, double u_theta)
+{
+    V3 random_dir = random_direction(u_z, u_theta);
+    V3 reflection_dir = vsub(ray_dir, vmuls(vmuls(surface_normal, 2.0), dot(ray_dir, surface_normal)));
+    V3 random_to_reflection_dir = vsub(reflection_dir, random_dir);
+    double reflection_mult = 1.0 - surface_roughness;
+    V3 final_direction = vadd(random_dir, vmuls(random_to_reflection_dir, reflection_mult));
+    final_direction = vnorm(final_direction);
+    if (dot(final_direction, surface_normal) > 0.0) return final_direction;
+    return vneg(final_direction);
+}
+
+// Object::normal_at of the winning object (object.rs:37-39)
+__device__ __forceinline__ V3 normal_at(const SceneView &sv, const Hit &h, V3 world_pos)
+{
+    if (h.kind == 0) return sphere_normal_at(sv.spheres[h.local], world_pos);
+    if (h.kind == 1) return sv.planes[h.local].nhat;
+    return sv.tris[h.local].nn;
+}
+
+// render_ray's Some((dst, obj)) arm (scene.rs:233-236) + ray_hit (scene.rs:260-278)
+__device__ __forceinline__ void advance_and_shade(const SceneView &sv, const Hit &h, RayState &r)
+{
+    r.pos = vadd(r.pos, vmuls(r.dir, h.t));                                    // scene.rs:234
+    const MaterialX m = sv.materials[h.id];
+    double u_z = rng_u01(r.key, r.draw);                                       // vector.rs:37
+    double u_theta = rng_u01(r.key, r.draw + 1);                               // vector.rs:38
+    r.draw += 2;
+    r.dir = random_bounce_dir(r.dir, normal_at(sv, h, r.pos), m.roughness, u_z, u_theta);  // scene.rs:275
+    r.result = vadd(r.result, vmulv(r.light, m.emission_color));               // scene.rs:276
+    r.light = vmulv(r.light, m.base_color);                                    // scene.rs:277
+    r.bounce += 1;
+}
+
+__device__ __forceinline__ bool light_is_zero(const RayState &r)               // scene.rs:228
+{
+    return r.light.x == 0.0 && r.light.y == 0.0 && r.light.z == 0.0;
+}
+
+}  // namespace rtx

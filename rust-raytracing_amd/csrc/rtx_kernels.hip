@@ -1,0 +1,500 @@
+// rtx_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the Scene::render hot path.
+//
+//   trace_exact_kernel  one thread per ray (pixel, sample); every shape test in f64 in the
+//                       reference's operation order.  The parity kernel.
+//   trace_mixed_kernel  persistent workgroups; each lane owns S ray slots whose f64 state lives in
+//                       HBM structure-of-arrays; the sphere list is staged through LDS in chunks as
+//                       16-byte f32 records and swept with a conservative f32 discriminant filter
+//                       (9 VALU ops per sphere per ray, one broadcast ds_read_b128 shared by 64*S
+//                       rays); candidates the filter cannot exclude are queued per slot in LDS and
+//                       re-evaluated exactly in f64, so the result has the same bits as
+//                       trace_exact_kernel.  Dead slots are refilled from a global ray queue with a
+//                       wave ballot + mbcnt prefix sum (one atomic per workgroup per round).
+//   resolve_kernel      left fold of a pixel's samples in sample order, then / rays_per_pixel.
+//   quantize_kernel     render_to_image epilogue.
+//
+// Compiled with -ffp-contract=off; the f32 filter uses explicit fmaf.
+#include "rtx_launch.h"
+
+namespace rtx {
+
+// ------------------------------------------------------------------------------------------
+// wave helpers (wave = 64 lanes on gfx950)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long mask)      // # set bits of mask below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void flush_counters(Counters *ctr, unsigned long long segs, unsigned long long exact,
+                                               unsigned long long filt)
+{
+    segs = wave_sum_u64(segs);
+    exact = wave_sum_u64(exact);
+    filt = wave_sum_u64(filt);
+    if (lane_id() == 0) {
+        uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kCounterShards - 1);
+        if (segs) atomicAdd(&ctr[shard].segments, segs);
+        if (exact) atomicAdd(&ctr[shard].exact_tests, exact);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+    }
+}
+
+// closest_object (scene.rs:243-251) over every shape of one type, exact f64.
+__device__ __forceinline__ void closest_spheres_exact(const SceneView &sv, const RayX &rx, Hit &h)
+{
+    for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+        double t;
+        if (sphere_distance(sv.spheres[k], rx, &t)) hit_consider(h, t, sv.sphere_id[k], 0, k);
+    }
+}
+
+__device__ __forceinline__ void closest_planes_exact(const SceneView &sv, const RayX &rx, Hit &h)
+{
+    for (uint32_t k = 0; k < sv.n_planes; ++k) {
+        double t;
+        if (plane_distance(sv.planes[k], rx, &t)) hit_consider(h, t, sv.planes[k].id, 1, k);
+    }
+}
+
+__device__ __forceinline__ void closest_tris_exact(const SceneView &sv, const RayX &rx, Hit &h)
+{
+    for (uint32_t k = 0; k < sv.n_tris; ++k) {
+        double t;
+        if (triangle_distance(sv.tris[k], rx, &t)) hit_consider(h, t, sv.tris[k].id, 2, k);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// EXACT kernel
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trace_exact_kernel(SceneView sv, RowsView rv, double *__restrict__ samples,
+                                                          Counters *__restrict__ ctr, uint64_t ray_offset)
+{
+    uint64_t i = ray_offset + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long segs = 0;
+    if (i < rv.n_rays) {
+        uint32_t pl, s_local;
+        ray_index_to_pixel(rv, i, pl, s_local);
+        RayState r;
+        gen_primary(sv, rv, pl, rv.sample_begin + s_local, r);
+        if (sv.n_objects != 0) {                                          // scene.rs:224-226
+            const uint64_t limit = sv.max_bounces + 1;                    // scene.rs:227
+            for (uint64_t b = 0; b < limit; ++b) {
+                if (light_is_zero(r)) break;                              // scene.rs:228
+                RayX rx = make_rayx(r.pos, r.dir);
+                Hit h;
+                hit_init(h);
+                ++segs;
+                closest_spheres_exact(sv, rx, h);
+                closest_planes_exact(sv, rx, h);
+                closest_tris_exact(sv, rx, h);
+                if (h.id == 0xFFFFFFFFu) break;                           // scene.rs:238
+                advance_and_shade(sv, h, r);
+            }
+        }
+        double *o = samples + ((uint64_t)s_local * rv.npix + pl) * 3;
+        o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+    }
+    flush_counters(ctr, segs, segs * sv.n_objects, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// MIXED kernel
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+// The f32 filter evaluates  D = ((c-p).d)^2 - (|c-p|^2 - r^2)  (a quarter of the reference's
+// discriminant for |d| = 1, sphere.rs:22-25) in the expanded form
+//     b = c.d - p.d            q = 2 c.p - p.p            D = b*b + (q - (c.c - r*r))
+// with all points relative to the scene centre.  The sphere record holds {c.xyz, c.c - r*r}; the
+// slot holds {d.xyz, -p.d, 2p.xyz, -p.p + E}.  E bounds the f32 evaluation error, so a sphere the
+// reference could report (discriminant > 1e-100) always has D_f32 + E >= 0 and is queued.
+struct FilterParams { float dx, dy, dz, npd, p2x, p2y, p2z, nppE; };
+
+__device__ __forceinline__ void filter_idle(FilterParams &f)
+{
+    f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
+    f.nppE = -__builtin_inff();                 // D = -inf: nothing passes
+}
+
+__device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
+{
+    // centre the origin (better conditioned f32 products); all in f64, then one rounding each
+    double px = pos.x - sv.sphere_center[0];
+    double py = pos.y - sv.sphere_center[1];
+    double pz = pos.z - sv.sphere_center[2];
+    double pp = px * px + py * py + pz * pz;
+    double pd = px * dir.x + py * dir.y + pz * dir.z;
+    // error bound: |D_f32 - D| <= 64 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md "filter bound")
+    double M = sv.sphere_cmax + sqrt(pp);
+    double E = M * M * (64.0 / 16777216.0);
+    f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
+    f.npd = (float)(-pd);
+    f.p2x = (float)(2.0 * px); f.p2y = (float)(2.0 * py); f.p2z = (float)(2.0 * pz);
+    f.nppE = (float)(E - pp);
+}
+
+__device__ __forceinline__ float filter_disc(const float4 s, const FilterParams &f)
+{
+    float b = __builtin_fmaf(s.x, f.dx, __builtin_fmaf(s.y, f.dy, __builtin_fmaf(s.z, f.dz, f.npd)));
+    float q = __builtin_fmaf(s.x, f.p2x, __builtin_fmaf(s.y, f.p2y, __builtin_fmaf(s.z, f.p2z, f.nppE)));
+    return __builtin_fmaf(b, b, q - s.w);
+}
+
+template <int S, int THREADS, int CHUNK, int Q>
+__global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, RowsView rv, double *__restrict__ samples,
+                                                              double *__restrict__ state, Counters *__restrict__ ctr,
+                                                              unsigned long long *__restrict__ work_counter,
+                                                              uint32_t verify, unsigned long long max_rounds)
+{
+    constexpr int WAVES = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *lds_sph = reinterpret_cast<float4 *>(smem);                                  // [CHUNK]
+    uint32_t *lds_q = reinterpret_cast<uint32_t *>(smem + (size_t)CHUNK * 16);           // [Q][S][THREADS]
+    uint32_t *lds_misc = lds_q + (size_t)Q * S * THREADS;                                // [WAVES + 4]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint64_t n_lanes = (uint64_t)gridDim.x * THREADS;         // SoA stride between slots of one lane
+    const uint64_t n_slots = n_lanes * S;                           // SoA stride between state fields
+    const uint64_t lane_gid = (uint64_t)blockIdx.x * THREADS + tid;
+    const uint32_t ns = sv.n_spheres;
+    const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
+
+    uint32_t pl[S], smp[S], bnc[S], cnt[S];
+    FilterParams fp[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { pl[s] = kInvalid; smp[s] = 0; bnc[s] = 0; cnt[s] = 0; filter_idle(fp[s]); }
+
+    unsigned long long segs = 0, exact = 0, filt = 0, mism = 0;
+
+    // Every round either advances every live ray by one segment or finds the queue drained, so a
+    // workgroup needs at most (rays / slots + 2) * (max_bounces + 1) rounds; max_rounds is that bound
+    // (computed by the launcher).  Hitting it means a logic error: the workgroup leaves and flags it.
+    for (unsigned long long round = 0;; ++round) {
+        if (round >= max_rounds) {
+            if (tid == 0) atomicAdd(&ctr[1].pad_, 1ull);
+            break;
+        }
+        // ---- refill idle slots from the global ray queue: ballot + prefix sum, one atomic per workgroup
+        unsigned long long idle_mask[S];
+        uint32_t wave_need = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            idle_mask[s] = __ballot(pl[s] == kInvalid);
+            wave_need += (uint32_t)__popcll(idle_mask[s]);
+        }
+        if (lane == 0) lds_misc[wave] = wave_need;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) total += lds_misc[w];
+            unsigned long long base = 0;
+            if (total) base = atomicAdd(work_counter, (unsigned long long)total);
+            lds_misc[WAVES] = (uint32_t)base;
+            lds_misc[WAVES + 1] = (uint32_t)(base >> 32);
+        }
+        __syncthreads();
+        {
+            unsigned long long base = ((unsigned long long)lds_misc[WAVES + 1] << 32) | lds_misc[WAVES];
+            for (uint32_t w = 0; w < wave; ++w) base += lds_misc[w];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (pl[s] == kInvalid) {
+                    unsigned long long my = base + mbcnt(idle_mask[s]);
+                    if (my < rv.n_rays) {
+                        uint32_t p, sl;
+                        ray_index_to_pixel(rv, my, p, sl);
+                        RayState r;
+                        gen_primary(sv, rv, p, rv.sample_begin + sl, r);
+                        pl[s] = p; smp[s] = sl; bnc[s] = 0;
+                        if (sv.n_objects == 0) {                                  // scene.rs:224-226
+                            double *o = samples + ((uint64_t)sl * rv.npix + p) * 3;
+                            o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
+                            pl[s] = kInvalid;
+                        } else {
+                            double *st = state + (lane_gid + (uint64_t)s * n_lanes);
+                            st[0 * n_slots] = r.pos.x; st[1 * n_slots] = r.pos.y; st[2 * n_slots] = r.pos.z;
+                            st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
+                            st[6 * n_slots] = 0.0; st[7 * n_slots] = 0.0; st[8 * n_slots] = 0.0;
+                            st[9 * n_slots] = 1.0; st[10 * n_slots] = 1.0; st[11 * n_slots] = 1.0;
+                            filter_from_ray(sv, r.pos, r.dir, fp[s]);
+                        }
+                    }
+                }
+                base += (unsigned long long)__popcll(idle_mask[s]);
+            }
+        }
+        // ---- workgroup-uniform exit: nothing live here and the queue handed out nothing
+        bool live = false;
+#pragma unroll
+        for (int s = 0; s < S; ++s) live |= (pl[s] != kInvalid);
+        if (__syncthreads_or(live ? 1 : 0) == 0) break;
+
+        // ---- sweep the sphere list through LDS with the f32 filter
+#pragma unroll
+        for (int s = 0; s < S; ++s) cnt[s] = 0;
+        for (uint32_t c0 = 0; c0 < ns; c0 += CHUNK) {
+            const uint32_t n = (ns - c0 < (uint32_t)CHUNK) ? ns - c0 : (uint32_t)CHUNK;
+            const uint32_t n4 = (n + 3u) & ~3u;
+            if (c0 != 0) __syncthreads();                  // everyone is done with the previous chunk
+            for (uint32_t j = tid; j < n4; j += THREADS) {
+                float4 v = make_float4(0.f, 0.f, 0.f, __builtin_inff());          // pad: never passes
+                if (j < n) v = sv.sphere_f32[c0 + j];
+                lds_sph[j] = v;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t j = 0; j < n4; j += 4) {
+                const float4 s0 = lds_sph[j], s1 = lds_sph[j + 1], s2 = lds_sph[j + 2], s3 = lds_sph[j + 3];
+                float d[S][4];
+                bool any = false;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    d[s][0] = filter_disc(s0, fp[s]);
+                    d[s][1] = filter_disc(s1, fp[s]);
+                    d[s][2] = filter_disc(s2, fp[s]);
+                    d[s][3] = filter_disc(s3, fp[s]);
+                    // !(x < 0): NaN (overflowing coordinates) passes and is settled by the exact test
+                    any |= !(d[s][0] < 0.f) | !(d[s][1] < 0.f) | !(d[s][2] < 0.f) | !(d[s][3] < 0.f);
+                }
+                if (any) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (!(d[s][k] < 0.f)) {
+                                if (cnt[s] < (uint32_t)Q) lds_q[((size_t)cnt[s] * S + s) * THREADS + tid] = c0 + j + k;
+                                cnt[s] += 1;                       // > Q marks overflow
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        filt += (unsigned long long)ns * S;        // counted per slot below would be exact; idle slots sweep too
+
+        // ---- exact f64 re-evaluation of the candidates, other shapes, shading
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (pl[s] != kInvalid) {
+                double *st = state + (lane_gid + (uint64_t)s * n_lanes);
+                RayState r;
+                r.pos = mk(st[0 * n_slots], st[1 * n_slots], st[2 * n_slots]);
+                r.dir = mk(st[3 * n_slots], st[4 * n_slots], st[5 * n_slots]);
+                const RayX rx = make_rayx(r.pos, r.dir);
+                Hit h;
+                hit_init(h);
+                ++segs;
+                if (cnt[s] > (uint32_t)Q) {
+                    // more candidates than the queue holds (many spheres along one line): exact sweep
+                    closest_spheres_exact(sv, rx, h);
+                    exact += ns;
+                } else {
+                    for (uint32_t k = 0; k < cnt[s]; ++k) {
+                        uint32_t idx = lds_q[((size_t)k * S + s) * THREADS + tid];
+                        if (idx < ns) {
+                            double t;
+                            if (sphere_distance(sv.spheres[idx], rx, &t)) hit_consider(h, t, sv.sphere_id[idx], 0, idx);
+                        }
+                    }
+                    exact += cnt[s];
+                    if (verify) {            // debug: the filter must never lose the exact winner
+                        Hit hv;
+                        hit_init(hv);
+                        closest_spheres_exact(sv, rx, hv);
+                        if (hv.id != h.id || (hv.id != kInvalid && hv.t != h.t)) ++mism;
+                    }
+                }
+                closest_planes_exact(sv, rx, h);
+                closest_tris_exact(sv, rx, h);
+                exact += sv.n_planes + sv.n_tris;
+
+                r.result = mk(st[6 * n_slots], st[7 * n_slots], st[8 * n_slots]);
+                bool done = true;
+                if (h.id != kInvalid) {                                            // scene.rs:233-236
+                    r.light = mk(st[9 * n_slots], st[10 * n_slots], st[11 * n_slots]);
+                    uint32_t k = pl[s] / rv.width;
+                    uint32_t x = pl[s] - k * rv.width;
+                    uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                    r.key = rng_key(sv.seed, pix, rv.sample_begin + smp[s]);
+                    r.draw = 6u + 2u * bnc[s];
+                    r.bounce = bnc[s];
+                    advance_and_shade(sv, h, r);
+                    bnc[s] = r.bounce;
+                    done = (r.bounce >= bounce_limit) || light_is_zero(r);         // scene.rs:227-228
+                    if (!done) {
+                        st[0 * n_slots] = r.pos.x; st[1 * n_slots] = r.pos.y; st[2 * n_slots] = r.pos.z;
+                        st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
+                        st[6 * n_slots] = r.result.x; st[7 * n_slots] = r.result.y; st[8 * n_slots] = r.result.z;
+                        st[9 * n_slots] = r.light.x; st[10 * n_slots] = r.light.y; st[11 * n_slots] = r.light.z;
+                        filter_from_ray(sv, r.pos, r.dir, fp[s]);
+                    }
+                }
+                if (done) {
+                    double *o = samples + ((uint64_t)smp[s] * rv.npix + pl[s]) * 3;
+                    o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+                    pl[s] = kInvalid;
+                    filter_idle(fp[s]);
+                }
+            }
+        }
+    }
+    flush_counters(ctr, segs, exact, filt);
+    if (verify) {
+        mism = wave_sum_u64(mism);
+        if (lane == 0 && mism) atomicAdd(&ctr[0].pad_, mism);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// resolve: avg() (scene.rs:253-259) = left fold from zeros (iter_ops.rs:4-8), then / len
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resolve_kernel(const double *__restrict__ samples, double *__restrict__ acc,
+                                                      double *__restrict__ out, uint32_t npix, uint32_t n_samples,
+                                                      double divisor, int first, int last)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    if (!first) { sx = acc[3 * (uint64_t)p]; sy = acc[3 * (uint64_t)p + 1]; sz = acc[3 * (uint64_t)p + 2]; }
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        const double *c = samples + ((uint64_t)s * npix + p) * 3;
+        sx = sx + c[0]; sy = sy + c[1]; sz = sz + c[2];
+    }
+    if (last) {
+        double *o = out + 3 * (uint64_t)p;
+        o[0] = sx / divisor; o[1] = sy / divisor; o[2] = sz / divisor;
+    } else {
+        acc[3 * (uint64_t)p] = sx; acc[3 * (uint64_t)p + 1] = sy; acc[3 * (uint64_t)p + 2] = sz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// render_to_image epilogue (scene.rs:175-178): img[height-1-y][x] * 256, Rust `as u8`
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t rust_as_u8(double v)
+{
+    if (!(v == v)) return 0;
+    if (v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+
+__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ rgb, uint8_t *__restrict__ rgb8,
+                                                       uint32_t width, uint32_t height)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t npix = (uint64_t)width * height;
+    if (p >= npix) return;
+    uint32_t y = (uint32_t)(p / width);
+    uint32_t x = (uint32_t)(p - (uint64_t)y * width);
+    const double *c = rgb + 3 * ((uint64_t)(height - y - 1) * width + x);
+    uint8_t *o = rgb8 + 3 * p;
+    o[0] = rust_as_u8(c[0] * 256.0);
+    o[1] = rust_as_u8(c[1] * 256.0);
+    o[2] = rust_as_u8(c[2] * 256.0);
+}
+
+__global__ void debug_math_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (op) {
+        case 0: r = a[i] / b[i]; break;
+        case 1: r = sqrt(a[i]); break;
+        case 2: r = sin(a[i]); break;
+        case 3: r = cos(a[i]); break;
+        default: { double sn, cs; sincos(a[i], &sn, &cs); r = (op == 4) ? sn : cs; } break;
+    }
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+hipError_t launch_trace_exact(const SceneView &sv, const RowsView &rv, double *samples, Counters *counters,
+                              hipStream_t stream)
+{
+    const uint64_t per_launch = 1ull << 30;                 // rays per launch (grid.x stays < 2^31)
+    for (uint64_t off = 0; off < rv.n_rays; off += per_launch) {
+        uint64_t n = rv.n_rays - off < per_launch ? rv.n_rays - off : per_launch;
+        uint32_t blocks = (uint32_t)((n + 255) / 256);
+        hipLaunchKernelGGL(trace_exact_kernel, dim3(blocks), dim3(256), 0, stream, sv, rv, samples, counters, off);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+namespace {
+constexpr int kMixS = 2, kMixThreads = 512, kMixChunk = 2048, kMixQ = 8;
+constexpr size_t kMixLds = (size_t)kMixChunk * 16 + (size_t)kMixQ * kMixS * kMixThreads * 4 + (kMixThreads / 64 + 4) * 4;
+}  // namespace
+
+size_t mixed_state_bytes(int n_cus)
+{
+    return (size_t)n_cus * 2 /*blocks per CU*/ * kMixThreads * kMixS * 12 * sizeof(double);
+}
+
+hipError_t launch_trace_mixed(const SceneView &sv, const RowsView &rv, double *samples, double *state, Counters *counters,
+                              unsigned long long *work_counter, int n_cus, bool verify, hipStream_t stream)
+{
+    auto kern = trace_mixed_kernel<kMixS, kMixThreads, kMixChunk, kMixQ>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMixLds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    uint64_t want = (rv.n_rays + (uint64_t)kMixThreads * kMixS - 1) / ((uint64_t)kMixThreads * kMixS);
+    uint64_t cap = (uint64_t)n_cus * 2;
+    uint32_t blocks = (uint32_t)(want < cap ? want : cap);
+    if (blocks == 0) return hipSuccess;
+    const unsigned long long limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0ull : sv.max_bounces + 1ull;
+    const unsigned long long max_rounds = (rv.n_rays / ((uint64_t)kMixThreads * kMixS) + 2ull) * limit + 4ull;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kMixThreads), kMixLds, stream, sv, rv, samples, state, counters,
+                       work_counter, verify ? 1u : 0u, max_rounds);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,
+                          uint64_t rays_per_pixel, bool first, bool last, hipStream_t stream)
+{
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, samples, acc, out, npix,
+                       n_samples, (double)rays_per_pixel, first ? 1 : 0, last ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize(const double *rgb, uint8_t *rgb8, uint32_t width, uint32_t height, hipStream_t stream)
+{
+    uint64_t npix = (uint64_t)width * height;
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_kernel, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, stream, rgb, rgb8, width,
+                       height);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_math(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(debug_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace rtx

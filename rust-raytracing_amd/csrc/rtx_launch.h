@@ -1,0 +1,33 @@
+// rtx_launch.h -- host-callable launchers of the gfx950 kernels (rtx_kernels.hip).
+#pragma once
+
+#include "rtx_device.h"
+
+namespace rtx {
+
+// samples: [n_samples][npix][3] doubles (one RGB per ray), written by the trace kernels.
+hipError_t launch_trace_exact(const SceneView &sv, const RowsView &rv, double *samples, Counters *counters,
+                              hipStream_t stream);
+
+// MIXED kernel: persistent workgroups, f32 sphere filter staged through LDS, exact f64 re-test of
+// candidates.  work_counter: one zeroed u64 on the device (ray queue head).
+// state: mixed_state_bytes(n_cus) bytes of device scratch (SoA ray state).  verify: also run the exact
+// sweep per segment and count disagreements into counters[0].pad_ (debug).
+size_t mixed_state_bytes(int n_cus);
+hipError_t launch_trace_mixed(const SceneView &sv, const RowsView &rv, double *samples, double *state,
+                              Counters *counters, unsigned long long *work_counter, int n_cus, bool verify,
+                              hipStream_t stream);
+
+// Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
+// sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.
+hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,
+                          uint64_t rays_per_pixel, bool first, bool last, hipStream_t stream);
+
+// render_to_image epilogue (scene.rs:175-178)
+hipError_t launch_quantize(const double *rgb, uint8_t *rgb8, uint32_t width, uint32_t height, hipStream_t stream);
+
+// device evaluation of single f64 ops (tests: are / and sqrt correctly rounded, how far are sin/cos)
+// op: 0 a/b, 1 sqrt(a), 2 sin(a), 3 cos(a)
+hipError_t launch_debug_math(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
+
+}  // namespace rtx
