@@ -205,6 +205,7 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
             if (total) base = atomicAdd(work_counter, (unsigned long long)total);
             lds_misc[WAVES] = (uint32_t)base;
             lds_misc[WAVES + 1] = (uint32_t)(base >> 32);
+            lds_misc[WAVES + 2] = 0;           // "some slot of this workgroup is live" (set below)
         }
         __syncthreads();
         {
@@ -241,7 +242,11 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
         bool live = false;
 #pragma unroll
         for (int s = 0; s < S; ++s) live |= (pl[s] != kInvalid);
-        if (__syncthreads_or(live ? 1 : 0) == 0) break;
+        if (__ballot(live) != 0ull && lane == 0) lds_misc[WAVES + 2] = 1;
+        __syncthreads();
+        // the flag is cleared by thread 0 between the two refill barriers of the NEXT round, i.e. after
+        // every wave has passed this read
+        if (lds_misc[WAVES + 2] == 0) break;
 
         // ---- sweep the sphere list through LDS with the f32 filter
 #pragma unroll
