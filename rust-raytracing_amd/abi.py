@@ -71,6 +71,26 @@ class RtxError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same SONAME as /opt/rocm's).  If it is mapped before librtx_hip.so, the dynamic
+    linker resolves our NEEDED libamdhip64.so.7 to it, and torch tensors' device pointers, streams and our
+    launches all live in one runtime.  torch itself is not imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen librtx_hip.so and bind every entry point.  Raises if the library is absent."""
     global _lib
@@ -80,6 +100,7 @@ def load_library():
         raise RuntimeError(
             "librtx_hip.so is not built (%s). Build it with `python rust-raytracing_amd/build.py` "
             "(hipcc, gfx950). There is no CPU fallback for the render path." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

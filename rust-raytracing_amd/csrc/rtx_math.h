@@ -51,7 +51,8 @@ RTX_HD double vlen(V3 a)                                             // vector.r
 RTX_HD V3 vnorm(V3 a) { return vdivs(a, vlen(a)); }                  // vector.rs:105-107
 
 // Counter-based RNG that stands in for fastrand's thread-local generator
-// (math/vector.rs:31-33,37-38).  Bit-identical to oracle/rtx_oracle.c rtxo_rng_key/rtxo_rng_u01.
+// (math/vector.rs:31-33,37-38).  Integer arithmetic only, so the test-suite's CPU checker can
+// reproduce every draw bit for bit (DESIGN.md "RNG").
 RTX_HD uint64_t mix64(uint64_t z)
 {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;

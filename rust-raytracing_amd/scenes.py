@@ -78,31 +78,52 @@ def random_triangles(n=100000, seed=2, box=1.0):
     return o
 
 
-def mixed_scene(n_spheres=40, n_tris=40, n_planes=1, seed=7):
-    """Small scene with all three shape kinds interleaved in scene order (tie-break / ordering tests)."""
-    s = random_spheres(n_spheres, seed)
-    t = random_triangles(n_tris, seed + 1)
-    # bring everything close to the camera so most rays hit something
-    s["geom"][:, 0] = 4.0 + (s["geom"][:, 0] - 10.0) * 0.08
-    s["geom"][:, 1] *= 0.08; s["geom"][:, 2] *= 0.08
-    s["geom"][:, 3] *= 0.6
-    tc = t["geom"].reshape(-1, 3, 3)
+def compact(objs, k=0.08, x0=4.0):
+    """Moves spheres/triangles of the C2/C3 recipes close to the camera (centres x -> x0 + (x-10)*k, y,z -> *k;
+    sphere radii * 0.6, triangle shapes kept) so that small test scenes have most rays hitting something."""
+    o = objs.copy()
+    sph = o["kind"] == RTX_SPHERE
+    tri = o["kind"] == RTX_TRIANGLE
+    g = o["geom"]
+    gs = g[sph]
+    gs[:, 0] = x0 + (gs[:, 0] - 10.0) * k
+    gs[:, 1] *= k
+    gs[:, 2] *= k
+    gs[:, 3] *= 0.6
+    g[sph] = gs
+    tc = g[tri].reshape(-1, 3, 3)
     cen = tc.mean(axis=1, keepdims=True)
     new_cen = cen.copy()
-    new_cen[..., 0] = 4.0 + (cen[..., 0] - 10.0) * 0.08
-    new_cen[..., 1] = cen[..., 1] * 0.08
-    new_cen[..., 2] = cen[..., 2] * 0.08
-    t["geom"] = (tc - cen + new_cen).reshape(-1, 9)
+    new_cen[..., 0] = x0 + (cen[..., 0] - 10.0) * k
+    new_cen[..., 1] = cen[..., 1] * k
+    new_cen[..., 2] = cen[..., 2] * k
+    g[tri] = (tc - cen + new_cen).reshape(-1, 9)
+    o["geom"] = g
+    return o
+
+
+def light_every(objs, n=4, gain=2.0):
+    """Turns every n-th object into a Material::light so that bounced paths pick up colour."""
+    o = objs.copy()
+    lit = np.arange(len(o)) % n == 0
+    o["emission_color"][lit] = (0.5 + 0.5 * o["base_color"][lit]) * gain + o["emission_color"][lit]
+    o["base_color"][lit] = 0.0
+    o["roughness"][lit] = 1.0
+    return o
+
+
+def mixed_scene(n_spheres=40, n_tris=40, n_planes=1, seed=7):
+    """Small scene with all three shape kinds interleaved in scene order (tie-break / ordering tests)."""
+    s = light_every(compact(random_spheres(n_spheres, seed)))
+    t = light_every(compact(random_triangles(n_tris, seed + 1)))
     p = np.zeros(n_planes, dtype=OBJECT_DTYPE)
     p["kind"] = RTX_PLANE
     for i in range(n_planes):
         p[i]["geom"][:6] = (0, 0, -4.5 - i, 0.05 * i, 0, 1)
         p[i]["base_color"] = (0.7, 0.7, 0.6)
         p[i]["roughness"] = 0.6
-    n = n_spheres + n_tris + n_planes
-    out = np.zeros(n, dtype=OBJECT_DTYPE)
-    # interleave: order = round-robin over the three lists
-    lists = [list(s), list(t), list(p)]
+    out = np.zeros(n_spheres + n_tris + n_planes, dtype=OBJECT_DTYPE)
+    lists = [list(s), list(t), list(p)]          # scene order = round-robin over the three kinds
     k = 0
     while any(lists):
         for lst in lists:

@@ -1,0 +1,254 @@
+"""Pins the CPU oracle: the reference's own known-answer tests (camera.rs:82-109), analytic cases of every
+shape, the RNG vectors and the committed golden images.  No GPU needed."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DEFAULT_CAM, oracle_render
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+X, Y, Z = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+
+
+def _cam_apply(oracle, cam, fn, v):
+    return getattr(oracle.lib(), fn)(C.byref(cam), oracle.vec(v)).tuple()
+
+
+# ---- the reference's own tests, verbatim (src/raytracing/camera.rs:82-109) --------------------
+def test_camera_from_world_space(oracle):                     # camera.rs:83-88
+    cam = oracle.camera_new((0, 0, 0), X, math.radians(90.0))
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_cam_space", X) == Z
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_cam_space", Y) == X
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_cam_space", Z) == Y
+
+
+def test_camera_from_cam_space(oracle):                       # camera.rs:90-95
+    cam = oracle.camera_new((0, 0, 0), X, math.radians(90.0))
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_world_space", X) == Y
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_world_space", Y) == Z
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_world_space", Z) == X
+
+
+def test_camera_from_cam_space_2(oracle):                     # camera.rs:97-102
+    cam = oracle.camera_new((0, 0, 0), Y, math.radians(90.0))
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_world_space", X) == (-1.0, 0.0, 0.0)
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_world_space", Y) == Z
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_world_space", Z) == Y
+
+
+def test_camera_from_world_space_2(oracle):                   # camera.rs:104-109
+    cam = oracle.camera_new((0, 0, 0), Y, math.radians(90.0))
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_cam_space", X) == (-1.0, 0.0, 0.0)
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_cam_space", Y) == Z
+    assert _cam_apply(oracle, cam, "rtxo_camera_to_cam_space", Z) == Y
+
+
+def test_camera_set_direction_lags_one_call(oracle):          # camera.rs:35-40 (reference quirk, restated)
+    cam = oracle.camera_new((0, 0, 0), X, 1.0)
+    before = _cam_apply(oracle, cam, "rtxo_camera_rotate_to_world_space", Z)
+    oracle.lib().rtxo_camera_set_direction(C.byref(cam), oracle.vec(Y))
+    assert _cam_apply(oracle, cam, "rtxo_camera_rotate_to_world_space", Z) == before      # still the old basis
+    oracle.lib().rtxo_camera_set_direction(C.byref(cam), oracle.vec(Y))
+    assert _cam_apply(oracle, cam, "rtxo_camera_rotate_to_world_space", Z) == Y           # now derived from Y
+
+
+# ---- analytic shape cases (pins 2) ---------------------------------------
+def test_sphere_distance_cases(oracle):                       # sphere.rs:19-30
+    assert oracle.sphere_distance((5, 0, 0), 1, (0, 0, 0), X) == 4.0
+    assert oracle.sphere_distance((5, 1, 0), 1, (0, 0, 0), X) is None            # tangent: discriminant 0 <= 1e-100
+    assert oracle.sphere_distance((5, 3, 0), 1, (0, 0, 0), X) is None            # miss
+    assert oracle.sphere_distance((0, 0, 0), 2, (0, 0, 0), X) == -2.0            # origin inside: near root is negative
+    assert oracle.sphere_distance((-5, 0, 0), 1, (0, 0, 0), X) == -6.0           # behind the ray
+    # un-normalised direction is normalised per call (sphere.rs:21)
+    assert oracle.sphere_distance((5, 0, 0), 1, (0, 0, 0), (3, 0, 0)) == 4.0
+
+
+def test_plane_distance_cases(oracle):                        # plane.rs:20-31
+    assert oracle.plane_distance((0, 0, -1), Z, (0, 0, 0), (0, 0, -1)) == 1.0
+    assert oracle.plane_distance((0, 0, -1), Z, (0, 0, 0), (0, 0, 1)) is None    # heading away
+    assert oracle.plane_distance((0, 0, -1), Z, (0, 0, -2), (0, 0, 1)) is None   # coming from behind
+    assert oracle.plane_distance((0, 0, -1), Z, (0, 0, 0), X) is None            # parallel (d.n == 0 -> >= 0)
+    d = oracle.plane_distance((0, 0, -1), (0, 0, 5), (0, 0, 0), (1 / math.sqrt(2), 0, -1 / math.sqrt(2)))
+    assert abs(d - math.sqrt(2)) < 1e-15
+
+
+TRI = ((5, -1, -1), (5, 1, -1), (5, 0, 1))
+
+
+def test_triangle_distance_cases(oracle):                     # triangle.rs:108-127 incl. its quirks
+    assert oracle.triangle_distance(*TRI, (0, 0, 0), X) == 5.0
+    # H2b: abs() of the signed plane distance -> a triangle entirely BEHIND the ray is still "hit"
+    assert oracle.triangle_distance(*TRI, (0, 0, 0), (-1, 0, 0)) == 5.0
+    d = (-1, 0.05, 0.02)
+    n = math.sqrt(sum(c * c for c in d))
+    assert oracle.triangle_distance(*TRI, (0, 0, 0), tuple(c / n for c in d)) == 5.007244751357777
+    # outside the (projected) triangle
+    assert oracle.triangle_distance(*TRI, (0, 0, 0), (1 / math.sqrt(2), 1 / math.sqrt(2), 0)) is None
+    # parallel to the plane: dir.dot(normal) == 0 -> INFINITY -> None (triangle.rs:31-33,119)
+    assert oracle.triangle_distance(*TRI, (0, 0, 0), Y) is None
+    # H2a: cull uses normal.(v0 - DIRECTION) < 0; this winding has n = (1,0,0)... reversed winding flips it
+    rev = (TRI[1], TRI[0], TRI[2])
+    nx = oracle.triangle_normal(*rev)[0]
+    assert nx == -1.0
+    assert oracle.triangle_distance(*rev, (0, 0, 0), X) is None                 # n.(v0 - dir) = -(5-1) < 0
+
+
+def test_triangle_degenerate_is_a_miss(oracle):               # triangle.rs:60-66,81-85 "can't handle LGS"
+    assert oracle.triangle_contains((0, 0, 0), (0, 1, 0), (0, 2, 0), (0, 0.5, 0)) == -1   # r.x = s.x = 0, collinear
+    # r = s = 0 in x for all rows -> first "can't handle"
+    assert oracle.triangle_contains((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)) == -1
+
+
+def test_triangle_row_swaps(oracle):                          # triangle.rs:60-71,81-87: pivot swaps
+    # r.x == 0 -> swap rows 1,2; triangle in the plane x = 2 with edges along y and z
+    t = ((2, 0, 0), (2, 1, 0), (2, 0, 1))
+    assert oracle.triangle_contains(*t, (2, 0.25, 0.25)) == 1
+    assert oracle.triangle_contains(*t, (2, 0.75, 0.75)) == 0
+    # r.x == r.y == 0 -> swap rows 1,3
+    t2 = ((0, 0, 0), (0, 0, 1), (1, 0, 0))
+    assert oracle.triangle_contains(*t2, (0.25, 0, 0.25)) == 1
+    # phantom: only two of three equations are solved, an off-plane point can be "inside" (H2c)
+    assert oracle.triangle_contains((0, 0, 0), (1, 0, 0), (0, 1, 0), (0.25, 0.25, 123.0)) == 1
+
+
+def test_triangle_self_hit_after_bounce(oracle):              # no epsilon anywhere
+    t = ((3.1, -1.3, -0.7), (3.4, 1.1, -0.9), (2.9, 0.2, 1.2))
+    d0 = np.array([1.0, 0.02, 0.01]); d0 /= np.linalg.norm(d0)
+    t0 = oracle.triangle_distance(*t, (0, 0, 0), tuple(d0))
+    assert t0 is not None and t0 > 0
+    p = tuple(float(t0 * c) for c in d0)                   # hit point, as scene.rs:234 computes it
+    n = oracle.triangle_normal(*t)
+    out = oracle.random_bounce_dir(tuple(d0), n, 1.0, 0.3, 0.6)
+    t1 = oracle.triangle_distance(*t, p, out)
+    # the origin lies on the triangle: the next segment re-hits it at |t| ~ 1e-16 (or exactly 0 -> filtered)
+    assert t1 is not None and abs(t1) < 1e-12
+
+
+# ---- RNG ------------------------------------------------------------------------------------------
+def test_rng_vectors_and_distribution(oracle):
+    with open(os.path.join(GOLDEN, "rng_vectors.json")) as f:
+        vec = json.load(f)
+    for v in vec:
+        assert oracle.lib().rtxo_rng_key(v["seed"], v["pixel"], v["sample"]) == v["key"]
+        for k, hx in enumerate(v["u"]):
+            assert oracle.rng_u01(v["seed"], v["pixel"], v["sample"], k) == float.fromhex(hx)
+    u = np.array([oracle.rng_u01(42, p, s, k) for p in range(50) for s in range(4) for k in range(10)])
+    assert u.min() >= 0.0 and u.max() < 1.0
+    assert np.all(u * 2.0 ** 52 == np.floor(u * 2.0 ** 52))          # fastrand::f64(): 52 mantissa bits
+    assert abs(u.mean() - 0.5) < 0.03 and abs(u.var() - 1 / 12) < 0.01
+
+
+def test_random_bounce_dir_properties(oracle):                # scene.rs:279-292
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        rough = float(rng.uniform())
+        out = np.array(oracle.random_bounce_dir(d, n, rough, rng.uniform(), rng.uniform()))
+        assert abs(np.linalg.norm(out) - 1.0) < 1e-14
+        assert out.dot(n) >= 0.0
+    # roughness 0 -> the mirror direction (up to the flip into n's hemisphere)
+    d = np.array([1.0, -1.0, 0.0]) / math.sqrt(2)
+    out = np.array(oracle.random_bounce_dir(d, (0, 1, 0), 0.0, 0.37, 0.81))
+    assert np.allclose(out, np.array([1.0, 1.0, 0.0]) / math.sqrt(2), atol=1e-15)
+
+
+# ---- whole-image properties that need no RNG agreement ---------------------
+def _lights(n, seed):
+    from rust_raytracing_amd import scenes
+    o = scenes.compact(scenes.random_spheres(n, seed))
+    o["base_color"] = 0.0
+    o["emission_color"] = np.round(np.random.default_rng(seed).uniform(0, 4, size=(n, 3)) * 8) / 8   # dyadic
+    o["roughness"] = 1.0
+    return o
+
+
+def test_emission_only_image_is_seed_independent(oracle):
+    objs = _lights(60, 5)
+    cfg = dict(rays_per_pixel=4, focal_offset=0.0, non_focal_offset=0.0)
+    a = oracle_render(oracle, objs, 40, 24, seed=1, **cfg)
+    b = oracle_render(oracle, objs, 40, 24, seed=999, **cfg)
+    assert np.array_equal(a, b)
+    # each pixel = emission of the first hit along the un-jittered primary ray
+    sc = oracle.make_scene(objs, DEFAULT_CAM, **cfg)
+    L = oracle.lib()
+    vfov = 24 / 40 * DEFAULT_CAM[2]
+    for (y, x) in [(0, 0), (12, 20), (23, 39), (7, 31)]:
+        d = L.rtxo_get_ray_dir(C.byref(sc), x / 40, y / 24, vfov)
+        nd = L.rtxo_norm(d)
+        dst = C.c_double()
+        # focal_point - origin = dir * focal_length; its norm() is what render_pixel traces (scene.rs:203-207)
+        fl = oracle.Vec3(d.x * 10.0, d.y * 10.0, d.z * 10.0)
+        nd = L.rtxo_norm(fl)
+        hit = L.rtxo_closest_object(C.byref(sc), oracle.vec((0, 0, 0)), nd, C.byref(dst))
+        want = objs[hit]["emission_color"] if hit >= 0 else np.zeros(3)
+        assert np.array_equal(a[y, x], want)
+
+
+def test_tie_break_first_object_wins(oracle):                 # scene.rs:250 min_by keeps the first minimum
+    from rust_raytracing_amd import scenes
+    o = scenes.three_spheres()[:2].copy()
+    o[0]["geom"][:4] = (6, 0, 0, 2); o[1]["geom"][:4] = (6, 0, 0, 2)
+    o["base_color"] = 0.0
+    o[0]["emission_color"] = (1, 0, 0); o[1]["emission_color"] = (0, 1, 0)
+    img = oracle_render(oracle, o, 16, 16, rays_per_pixel=1, focal_offset=0.0, non_focal_offset=0.0)
+    assert img[8, 8].tolist() == [1.0, 0.0, 0.0]
+    img = oracle_render(oracle, o[::-1].copy(), 16, 16, rays_per_pixel=1, focal_offset=0.0, non_focal_offset=0.0)
+    assert img[8, 8].tolist() == [0.0, 1.0, 0.0]
+
+
+def test_empty_scene_and_zero_samples(oracle):
+    from rust_raytracing_amd import abi
+    empty = np.zeros(0, dtype=abi.OBJECT_DTYPE)
+    img = oracle_render(oracle, empty, 8, 4, rays_per_pixel=3)
+    assert img.shape == (4, 8, 3) and not img.any()                     # scene.rs:224-226
+    from rust_raytracing_amd import scenes
+    img = oracle_render(oracle, scenes.three_spheres(), 8, 4, rays_per_pixel=0)
+    assert np.isnan(img).all()                                          # avg of nothing: 0/0 (scene.rs:253-259)
+
+
+def test_faithful_mode_equals_clean_mode(oracle):
+    from rust_raytracing_amd import scenes
+    objs = scenes.mixed_scene()
+    sc = oracle.make_scene(objs, DEFAULT_CAM, rays_per_pixel=2)
+    a = oracle.render(sc, 24, 16, n_threads=3, mode=oracle.MODE_CLEAN)
+    b = oracle.render(sc, 24, 16, mode=oracle.MODE_FAITHFUL)
+    c = oracle.render(sc, 24, 16, n_threads=1, mode=oracle.MODE_CLEAN)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_row_partition_is_invisible(oracle):
+    from rust_raytracing_amd import scenes
+    sc = oracle.make_scene(scenes.three_spheres(), DEFAULT_CAM, rays_per_pixel=2)
+    full = oracle.render(sc, 20, 15)
+    part = np.zeros_like(full)
+    for r in range(3):
+        tmp = oracle.render(sc, 20, 15, row_begin=r, row_stride=3)
+        part[r::3] = tmp[r::3]
+    assert np.array_equal(full, part)
+
+
+def test_quantize_image(oracle):                              # scene.rs:175-178
+    rgb = np.zeros((2, 3, 3))
+    rgb[0, 0] = (0.5, 1.0, 2.0)            # 128, 256 -> 255, 512 -> 255
+    rgb[0, 1] = (-0.3, np.nan, 0.999)      # 0, 0, 255 (255.744 truncates to 255)
+    rgb[1, 2] = (1 / 256, 0.00389, 254.5 / 256)
+    q = oracle.quantize_image(rgb)
+    assert q[1, 0].tolist() == [128, 255, 255]          # vertical flip: image row 1 = render row 0
+    assert q[1, 1].tolist() == [0, 0, 255]
+    assert q[0, 2].tolist() == [1, 0, 254]
+
+
+# ---- committed golden images --------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["c1_three_spheres_32x32", "spheres200_48x27", "mixed_40x24", "tris300_32x18"])
+def test_oracle_reproduces_golden(oracle, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    objs = np.frombuffer(z["objects"].tobytes(), dtype=oracle.OBJECT_DTYPE)
+    cfg = json.loads(str(z["config"]))
+    img, seg = oracle_render(oracle, objs, int(z["width"]), int(z["height"]), want_segments=True, **cfg)
+    assert np.array_equal(img, z["image"])
+    assert np.array_equal(seg, z["segments"])
