@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X: Mrays/s (primary rays, whole node) of the
+Scene::render hot path on the 10k-sphere 1920x1080 scene (configs[1], "C2").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = one full render of the frame: every rank traces its interleaved row band of the image with the
+MIXED HIP kernel (scene resident in HBM before the timed region), then ONE gather (RCCL over xGMI)
+brings the bands to rank 0.  Scaling is weak: the frame is fixed at 1920x1080 and rays_per_pixel = 64 * N,
+so every GPU traces the same number of primary rays (132.7 M) whatever N is.  value = all ranks' primary
+rays / (max-over-ranks time of the K steps).
+
+The same JSON line carries
+  roofline      logical operand bandwidth of the trace kernel (segments x n_spheres x 16 B per launch, SURVEY
+                8d / DESIGN.md) / its average duration measured with hipEvents on the launch stream, against
+                the 8 TB/s HBM peak.  The list is LDS/L2-resident by design, so frac may exceed 1: the kernel is
+                VALU-bound, and valu_frac gives the fraction of the VALU issue ceiling beside it.
+  cpu_baseline  the CPU oracle (a C restatement of the reference's CPU path: kind "port"; the Rust crate cannot
+                be built here) timed on this host's cores on a bounded sample of the same scene.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                       # noqa: E402  (first: one HIP runtime for torch tensors and librtx_hip)
+import torch.distributed as dist   # noqa: E402
+
+WIDTH, HEIGHT, SPP_PER_GPU, N_SPHERES = 1920, 1080, 64, 10000
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9      # 256 CU x 4 SIMD-32 x 2.4 GHz
+FILTER_OPS_PER_TEST = 9.0          # VALU instructions of the f32 sphere filter per (ray, sphere)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=None, help="rays per pixel per GPU (default 64: the named config)")
+    ap.add_argument("--kernel", type=int, default=2, help="1 exact f64, 2 mixed (default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="240x135x1", help="WxHxSPP sample of the same scene for the CPU leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample):
+    """The oracle on this host's cores, bounded sample of the same 10k-sphere scene (rank 0, N=1 only).
+
+    clean mode (thread pool = cores, no locks) renders WxH' with H' = max(H, 4*cores) rows so that every core
+    has rows to pull; faithful mode (one OS thread per row + a mutex per object, as scene.rs:151 / object.rs:50)
+    renders WxH."""
+    from oracle import rtx_oracle as oracle
+    from rust_raytracing_amd import scenes
+    w, h, spp = (int(v) for v in sample.split("x"))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    objs = scenes.random_spheres(N_SPHERES, 1)
+    sc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=spp, seed=scenes.RENDER_SEED)
+    out = {}
+    for mode, name, hh in ((oracle.MODE_CLEAN, "clean", max(h, 4 * cores)), (oracle.MODE_FAITHFUL, "faithful", h)):
+        t0 = time.perf_counter()
+        _, seg = oracle.render(sc, w, hh, n_threads=cores, mode=mode, want_segments=True)
+        dt = time.perf_counter() - t0
+        out[name] = (w * hh * spp / dt / 1e6, int(seg.sum()) / dt / 1e6, dt, w * hh * spp, hh)
+    best = max(out, key=lambda k: out[k][0])
+    return {
+        "value": out[best][0], "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": "same 10k-sphere scene, %dx%d px x %d spp (%d primary rays), f64 C restatement of the reference "
+                  "CPU path (the Rust crate cannot be built here), mode=%s" % (w, out[best][4], spp, out[best][3], best),
+        "clean_Mrays_s": out["clean"][0], "faithful_Mrays_s": out["faithful"][0],
+        "Msegments_s": out[best][1], "seconds": out["clean"][2] + out["faithful"][2],
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import rust_raytracing_amd as rtx
+    from rust_raytracing_amd import scenes, tiles
+
+    spp_per_gpu = args.spp if args.spp is not None else SPP_PER_GPU
+    spp = spp_per_gpu * world                                  # weak scaling: fixed rays per GPU
+    objs = scenes.random_spheres(N_SPHERES, 1)
+    cfg = rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=args.kernel)
+    scene = rtx.Scene.from_packed(cfg, rtx.Camera(*scenes.CAMERA), objs)
+    handle = scene.upload(local_rank)                          # scene resident in HBM before the timed region
+    rb, rs, n_rows = tiles.rows_for_rank(HEIGHT, rank, world)
+    band = tiles.alloc_band(HEIGHT, WIDTH, world, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        st = handle.render_rows(WIDTH, HEIGHT, rb, rs, n_rows, band.data_ptr(), stream=stream)
+        full = tiles.gather_bands(band, HEIGHT, WIDTH, rank, world, dst=0)
+        return st, full
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    trace_ms, segments, filt, exact = 0.0, 0, 0, 0
+    full = None
+    for _ in range(args.steps):
+        st, full = step()
+        trace_ms += st.trace_ms
+        segments += st.segments
+        filt += st.filter_tests
+        exact += st.exact_tests
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, trace_ms, float(segments)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_segments = int(tsum[2])
+    else:
+        total_segments = segments
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        rays_per_step = WIDTH * HEIGHT * spp
+        value = rays_per_step * args.steps / elapsed / 1e6 if args.steps else 0.0
+        mean = float(full.mean()) if full is not None else float("nan")
+        # dominant kernel = trace kernel of THIS rank: algorithmic bytes per launch / average launch duration
+        seg_per_launch = segments / steps
+        bytes_per_launch = seg_per_launch * N_SPHERES * 16.0
+        avg_ms = trace_ms / steps
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                rec = json.load(open(tj)).get("c2_%dspp_kernel%d" % (spp_per_gpu, args.kernel))
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "trace_mixed_kernel" if args.kernel != 1 else "trace_exact_kernel",
+            "avg_launch_ms": avg_ms, "segments_per_launch": seg_per_launch,
+            "algorithmic_bytes_per_segment": N_SPHERES * 16,
+            "note": "logical operand bandwidth (list is LDS/L2-resident by design; may exceed the HBM peak)",
+            "valu_frac": (filt / steps * FILTER_OPS_PER_TEST) / (avg_ms * 1e-3) / VALU_LANE_OPS_PER_S if avg_ms > 0 and filt else None,
+        }
+        line = {
+            "metric": "Mrays/s (primary rays, whole node), 10k-sphere 1080p 64spp",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: 10k random spheres (scene seed 1), 1920x1080, %d spp per GPU (%d total), "
+                                   "max_bounces 10, render seed 42" % (spp_per_gpu, spp),
+                       "width": WIDTH, "height": HEIGHT, "rays_per_pixel": spp, "n_spheres": N_SPHERES,
+                       "partition": "interleaved row bands, 1 gather" if world > 1 else "single GPU",
+                       "kernel": "mixed (f32 LDS filter + exact f64)" if args.kernel != 1 else "exact f64"},
+            "Msegments_per_s": total_segments / elapsed / 1e6,
+            "segments_per_primary_ray": total_segments / (rays_per_step * steps),
+            "image_mean": mean,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu"] = value / cb["value"] if cb["value"] > 0 else None
+        print(json.dumps(line), flush=True)
+    handle.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

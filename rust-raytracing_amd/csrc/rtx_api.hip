@@ -231,8 +231,12 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
                                                      " has no device primitive (user CustomShape impls cannot run on the GPU)");
         }
     }
-    // f32 filter records, relative to the centre of the spheres' bounding box
-    std::vector<float4> sph32(spheres.size());
+    // f32 filter records, relative to the centre of the spheres' bounding box, pair-interleaved for
+    // v_pk_fma_f32: record 2k = {x[2k], x[2k+1], y[2k], y[2k+1]}, record 2k+1 = {z.., w..}, w = |c|^2 - r^2;
+    // padded to a multiple of 4 spheres with a sentinel that never passes (w = 1e30)
+    const size_t ns4 = (spheres.size() + 3) & ~(size_t)3;
+    std::vector<float4> sph32(ns4);
+    std::vector<float> fx(ns4, 0.f), fy(ns4, 0.f), fz(ns4, 0.f), fw(ns4, 1.0e30f);
     double centre[3] = { 0, 0, 0 };
     for (int c = 0; c < 3; ++c) if (lo[c] <= hi[c]) centre[c] = 0.5 * (lo[c] + hi[c]);
     double cmax = 0.0;
@@ -241,8 +245,12 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
         double cx = o.geom[0] - centre[0], cy = o.geom[1] - centre[1], cz = o.geom[2] - centre[2];
         double cc = cx * cx + cy * cy + cz * cz;
         double reach = std::sqrt(cc) + std::fabs(o.geom[3]);
-        if (!(reach <= cmax)) cmax = reach;                   // NaN/inf propagate: the filter then passes everything
-        sph32[k] = make_float4((float)cx, (float)cy, (float)cz, (float)(cc - spheres[k].rr));
+        if (!(reach <= cmax)) cmax = reach;                   // NaN/inf propagate: every ray then takes the exact sweep
+        fx[k] = (float)cx; fy[k] = (float)cy; fz[k] = (float)cz; fw[k] = (float)(cc - spheres[k].rr);
+    }
+    for (size_t k = 0; k < ns4; k += 2) {
+        sph32[k] = make_float4(fx[k], fx[k + 1], fy[k], fy[k + 1]);
+        sph32[k + 1] = make_float4(fz[k], fz[k + 1], fw[k], fw[k + 1]);
     }
     h->sv.n_objects = (uint32_t)n;
     h->sv.n_spheres = (uint32_t)spheres.size();

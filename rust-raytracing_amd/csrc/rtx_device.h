@@ -24,7 +24,8 @@ struct SceneView {
     const TriX     *tris;
     const MaterialX *materials;                // by scene index
     // f32 filter records for the MIXED kernel
-    const float4   *sphere_f32;                // {c - centre (xyz), |c - centre|^2 - r*r}
+    const float4   *sphere_f32;                // pair-interleaved {x0,x1,y0,y1},{z0,z1,w0,w1}; c - centre, w = |c|^2 - r*r;
+                                               // padded to a multiple of 4 spheres
     double          sphere_center[3];          // centre of the spheres' bounding box
     double          sphere_cmax;               // max over spheres of |c - centre| + r
 };

@@ -115,19 +115,25 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
 // The f32 filter evaluates  D = ((c-p).d)^2 - (|c-p|^2 - r^2)  (a quarter of the reference's
 // discriminant for |d| = 1, sphere.rs:22-25) in the expanded form
-//     b = c.d - p.d            q = 2 c.p - p.p            D = b*b + (q - (c.c - r*r))
-// with all points relative to the scene centre.  The sphere record holds {c.xyz, c.c - r*r}; the
-// slot holds {d.xyz, -p.d, 2p.xyz, -p.p + E}.  E bounds the f32 evaluation error, so a sphere the
-// reference could report (discriminant > 1e-100) always has D_f32 + E >= 0 and is queued.
+//     b = c.d - p.d            q = 2 c.p - p.p + E            D = b*b + (q - (c.c - r*r))
+// with all points relative to the scene centre.  E bounds the f32 evaluation error, so a sphere the
+// reference could report (discriminant > 1e-100) always has D_f32 >= 0 and is queued.
+// Two spheres are evaluated per instruction (v_pk_fma_f32): LDS holds the records pair-interleaved,
+//     float4 A = {x0, x1, y0, y1}   float4 B = {z0, z1, w0, w1},   w = |c|^2 - r^2
+// and the slot holds {d.xyz, -p.d, 2p.xyz, -p.p + E}.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct FilterParams { float dx, dy, dz, npd, p2x, p2y, p2z, nppE; };
 
 __device__ __forceinline__ void filter_idle(FilterParams &f)
 {
     f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
-    f.nppE = -__builtin_inff();                 // D = -inf: nothing passes
+    f.nppE = -1.0e30f;                          // D = -1e30 - w: nothing passes (|w| < 1e30, see below)
 }
 
-__device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
+// Returns false when the magnitudes are too large for the f32 filter (it could overflow to inf/NaN);
+// the slot then takes the exact sweep.  Below the limit every filter operation stays finite, so the
+// sign-bit test of the sweep is exact: D >= 0 <=> sign bit clear.
+__device__ __forceinline__ bool filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
 {
     // centre the origin (better conditioned f32 products); all in f64, then one rounding each
     double px = pos.x - sv.sphere_center[0];
@@ -137,18 +143,26 @@ __device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 
     double pd = px * dir.x + py * dir.y + pz * dir.z;
     // error bound: |D_f32 - D| <= 64 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md "filter bound")
     double M = sv.sphere_cmax + sqrt(pp);
+    if (!(M < 1.0e14)) { filter_idle(f); return false; }
     double E = M * M * (64.0 / 16777216.0);
     f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
     f.npd = (float)(-pd);
     f.p2x = (float)(2.0 * px); f.p2y = (float)(2.0 * py); f.p2z = (float)(2.0 * pz);
     f.nppE = (float)(E - pp);
+    return true;
 }
 
-__device__ __forceinline__ float filter_disc(const float4 s, const FilterParams &f)
+// D for the two spheres of one LDS pair record
+__device__ __forceinline__ f32x2 filter_disc2(const float4 A, const float4 B, const FilterParams &f)
 {
-    float b = __builtin_fmaf(s.x, f.dx, __builtin_fmaf(s.y, f.dy, __builtin_fmaf(s.z, f.dz, f.npd)));
-    float q = __builtin_fmaf(s.x, f.p2x, __builtin_fmaf(s.y, f.p2y, __builtin_fmaf(s.z, f.p2z, f.nppE)));
-    return __builtin_fmaf(b, b, q - s.w);
+    const f32x2 x = {A.x, A.y}, y = {A.z, A.w}, z = {B.x, B.y}, w = {B.z, B.w};
+    f32x2 b = __builtin_elementwise_fma(z, (f32x2){f.dz, f.dz}, (f32x2){f.npd, f.npd});
+    b = __builtin_elementwise_fma(y, (f32x2){f.dy, f.dy}, b);
+    b = __builtin_elementwise_fma(x, (f32x2){f.dx, f.dx}, b);
+    f32x2 q = __builtin_elementwise_fma(z, (f32x2){f.p2z, f.p2z}, (f32x2){f.nppE, f.nppE});
+    q = __builtin_elementwise_fma(y, (f32x2){f.p2y, f.p2y}, q);
+    q = __builtin_elementwise_fma(x, (f32x2){f.p2x, f.p2x}, q);
+    return __builtin_elementwise_fma(b, b, q - w);
 }
 
 template <int S, int THREADS, int CHUNK, int Q>
@@ -173,9 +187,10 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
     uint32_t pl[S], smp[S], bnc[S], cnt[S];
+    bool force_exact[S];
     FilterParams fp[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) { pl[s] = kInvalid; smp[s] = 0; bnc[s] = 0; cnt[s] = 0; filter_idle(fp[s]); }
+    for (int s = 0; s < S; ++s) { pl[s] = kInvalid; smp[s] = 0; bnc[s] = 0; cnt[s] = 0; force_exact[s] = false; filter_idle(fp[s]); }
 
     unsigned long long segs = 0, exact = 0, filt = 0, mism = 0;
 
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
                             st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
                             st[6 * n_slots] = 0.0; st[7 * n_slots] = 0.0; st[8 * n_slots] = 0.0;
                             st[9 * n_slots] = 1.0; st[10 * n_slots] = 1.0; st[11 * n_slots] = 1.0;
-                            filter_from_ray(sv, r.pos, r.dir, fp[s]);
+                            force_exact[s] = !filter_from_ray(sv, r.pos, r.dir, fp[s]);
                         }
                     }
                 }
@@ -250,37 +265,32 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
 
         // ---- sweep the sphere list through LDS with the f32 filter
 #pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = 0;
+        for (int s = 0; s < S; ++s) cnt[s] = force_exact[s] ? (uint32_t)Q + 1u : 0u;
         for (uint32_t c0 = 0; c0 < ns; c0 += CHUNK) {
             const uint32_t n = (ns - c0 < (uint32_t)CHUNK) ? ns - c0 : (uint32_t)CHUNK;
-            const uint32_t n4 = (n + 3u) & ~3u;
+            const uint32_t n4 = (n + 3u) & ~3u;            // the device array is padded to a multiple of 4
             if (c0 != 0) __syncthreads();                  // everyone is done with the previous chunk
-            for (uint32_t j = tid; j < n4; j += THREADS) {
-                float4 v = make_float4(0.f, 0.f, 0.f, __builtin_inff());          // pad: never passes
-                if (j < n) v = sv.sphere_f32[c0 + j];
-                lds_sph[j] = v;
-            }
+            for (uint32_t j = tid; j < n4; j += THREADS) lds_sph[j] = sv.sphere_f32[c0 + j];
             __syncthreads();
 #pragma unroll 1
             for (uint32_t j = 0; j < n4; j += 4) {
-                const float4 s0 = lds_sph[j], s1 = lds_sph[j + 1], s2 = lds_sph[j + 2], s3 = lds_sph[j + 3];
-                float d[S][4];
-                bool any = false;
+                const float4 A0 = lds_sph[j], B0 = lds_sph[j + 1], A1 = lds_sph[j + 2], B1 = lds_sph[j + 3];
+                f32x2 d[S][2];
+                uint32_t sign_and = 0xFFFFFFFFu;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    d[s][0] = filter_disc(s0, fp[s]);
-                    d[s][1] = filter_disc(s1, fp[s]);
-                    d[s][2] = filter_disc(s2, fp[s]);
-                    d[s][3] = filter_disc(s3, fp[s]);
-                    // !(x < 0): NaN (overflowing coordinates) passes and is settled by the exact test
-                    any |= !(d[s][0] < 0.f) | !(d[s][1] < 0.f) | !(d[s][2] < 0.f) | !(d[s][3] < 0.f);
+                    d[s][0] = filter_disc2(A0, B0, fp[s]);
+                    d[s][1] = filter_disc2(A1, B1, fp[s]);
+                    sign_and &= __float_as_uint(d[s][0].x) & __float_as_uint(d[s][0].y) &
+                                __float_as_uint(d[s][1].x) & __float_as_uint(d[s][1].y);
                 }
-                if (any) {
+                if ((int)sign_and >= 0) {                  // some D has its sign bit clear: D >= 0
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            if (!(d[s][k] < 0.f)) {
+                            const float dk = (k & 1) ? d[s][k >> 1].y : d[s][k >> 1].x;
+                            if ((int)__float_as_uint(dk) >= 0) {
                                 if (cnt[s] < (uint32_t)Q) lds_q[((size_t)cnt[s] * S + s) * THREADS + tid] = c0 + j + k;
                                 cnt[s] += 1;                       // > Q marks overflow
                             }
@@ -345,13 +355,14 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
                         st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
                         st[6 * n_slots] = r.result.x; st[7 * n_slots] = r.result.y; st[8 * n_slots] = r.result.z;
                         st[9 * n_slots] = r.light.x; st[10 * n_slots] = r.light.y; st[11 * n_slots] = r.light.z;
-                        filter_from_ray(sv, r.pos, r.dir, fp[s]);
+                        force_exact[s] = !filter_from_ray(sv, r.pos, r.dir, fp[s]);
                     }
                 }
                 if (done) {
                     double *o = samples + ((uint64_t)smp[s] * rv.npix + pl[s]) * 3;
                     o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
                     pl[s] = kInvalid;
+                    force_exact[s] = false;
                     filter_idle(fp[s]);
                 }
             }
