@@ -143,7 +143,7 @@ __device__ __forceinline__ bool filter_from_ray(const SceneView &sv, V3 pos, V3 
     double pd = px * dir.x + py * dir.y + pz * dir.z;
     // error bound: |D_f32 - D| <= 64 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md "filter bound")
     double M = sv.sphere_cmax + sqrt(pp);
-    if (!(M < 1.0e14)) { filter_idle(f); return false; }
+    if (!(M < 1.0e14) || !(M > 1.0e-12)) { filter_idle(f); return false; }   // no overflow, E stays a normal f32
     double E = M * M * (64.0 / 16777216.0);
     f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
     f.npd = (float)(-pd);
