@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtx_hip.so")
+LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(HERE, "librtx_hip.so")   # RTX_HIP_LIB: A/B builds
 
 RTX_SPHERE, RTX_PLANE, RTX_TRIANGLE = 0, 1, 2
 RTX_KERNEL_AUTO, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY = 0, 1, 2, 3

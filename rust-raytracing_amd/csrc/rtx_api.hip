@@ -73,6 +73,8 @@ struct RtxSceneHandle_ {
     double *state = nullptr;    size_t state_bytes = 0;
     Counters *counters = nullptr;
     unsigned long long *work_counter = nullptr;
+    SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
+    RowsView *d_rv = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     // what the trig tables currently hold
     uint32_t t_w = 0, t_h = 0, t_rb = 0, t_rs = 0, t_nr = 0;
@@ -104,6 +106,7 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
     h->sv.focal_offset = cfg.focal_offset;
     h->sv.non_focal_offset = cfg.non_focal_offset;
     h->sv.seed = cfg.seed;
+    h->sv_dirty = true;
 }
 
 int32_t check_config(const RtxConfig &cfg)
@@ -137,6 +140,8 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->state) (void)hipFree(h->state);
     if (h->counters) (void)hipFree(h->counters);
     if (h->work_counter) (void)hipFree(h->work_counter);
+    if (h->d_sv) (void)hipFree(h->d_sv);
+    if (h->d_rv) (void)hipFree(h->d_rv);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -248,6 +253,11 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
         if (!(reach <= cmax)) cmax = reach;                   // NaN/inf propagate: every ray then takes the exact sweep
         fx[k] = (float)cx; fy[k] = (float)cy; fz[k] = (float)cz; fw[k] = (float)(cc - spheres[k].rr);
     }
+    if (!(cmax < 1.0e14)) {
+        // non-finite or enormous sphere data: the f32 records cannot represent it.  Every record becomes
+        // "always a candidate" (w = -1e30), so every ray overflows its queue and takes the exact f64 sweep.
+        for (size_t k = 0; k < ns4; ++k) { fx[k] = fy[k] = fz[k] = 0.f; fw[k] = -1.0e30f; }
+    }
     for (size_t k = 0; k < ns4; k += 2) {
         sph32[k] = make_float4(fx[k], fx[k + 1], fy[k], fy[k + 1]);
         sph32[k + 1] = make_float4(fz[k], fz[k + 1], fw[k], fw[k + 1]);
@@ -274,6 +284,8 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
 
     hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
     if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_sv, sizeof(SceneView));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_rv, sizeof(RowsView));
     for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
     if (e != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, std::string("scene scratch: ") + hipGetErrorString(e)); }
     *out = h;
@@ -371,6 +383,10 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     rv.sin_x = h->tables; rv.cos_x = h->tables + width;
     rv.sin_y = h->tables + 2 * (size_t)width; rv.cos_y = rv.sin_y + n_rows;
 
+    if (h->sv_dirty) {
+        RTX_HIP_CHECK(hipMemcpyAsync(h->d_sv, &h->sv, sizeof(SceneView), hipMemcpyHostToDevice, stream));
+        h->sv_dirty = false;
+    }
     RTX_HIP_CHECK(hipMemsetAsync(h->counters, 0, sizeof(Counters) * kCounterShards, stream));
     float trace_ms = 0.f, resolve_ms = 0.f;
     uint32_t launches = 0;
@@ -384,12 +400,13 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         rv.sample_begin = (uint32_t)s0;
         rv.n_samples = (uint32_t)ns;
         rv.n_rays = (uint64_t)npix * ns;
+        RTX_HIP_CHECK(hipMemcpyAsync(h->d_rv, &rv, sizeof(RowsView), hipMemcpyHostToDevice, stream));   // pageable: staged before return
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
         if (kernel == RTX_KERNEL_EXACT) {
-            RTX_HIP_CHECK(launch_trace_exact(h->sv, rv, h->samples, h->counters, stream));
+            RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            RTX_HIP_CHECK(launch_trace_mixed(h->sv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,
+            RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,
                                              kernel == RTX_KERNEL_MIXED_VERIFY, stream));
         }
         ++launches;

@@ -16,6 +16,8 @@
 // Compiled with -ffp-contract=off; the f32 filter uses explicit fmaf.
 #include "rtx_launch.h"
 
+#include <cstdlib>
+
 namespace rtx {
 
 // ------------------------------------------------------------------------------------------
@@ -77,9 +79,14 @@ __device__ __forceinline__ void closest_tris_exact(const SceneView &sv, const Ra
 // ------------------------------------------------------------------------------------------
 // EXACT kernel
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trace_exact_kernel(SceneView sv, RowsView rv, double *__restrict__ samples,
-                                                          Counters *__restrict__ ctr, uint64_t ray_offset)
+__global__ __launch_bounds__(256) void trace_exact_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
+                                                          double *__restrict__ samples, Counters *__restrict__ ctr,
+                                                          uint64_t ray_offset)
 {
+    // scene and launch descriptors live in device memory (not in the kernarg segment): fields are
+    // (re)loaded where they are used instead of pinning ~100 SGPRs for the whole kernel
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
     uint64_t i = ray_offset + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long segs = 0;
     if (i < rv.n_rays) {
@@ -124,16 +131,22 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct FilterParams { float dx, dy, dz, npd, p2x, p2y, p2z, nppE; };
 
-__device__ __forceinline__ void filter_idle(FilterParams &f)
+__device__ __forceinline__ void filter_idle(FilterParams &f)      // D = -3e30 - w < 0: nothing passes
 {
     f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
-    f.nppE = -1.0e30f;                          // D = -1e30 - w: nothing passes (|w| < 1e30, see below)
+    f.nppE = -3.0e30f;
 }
 
-// Returns false when the magnitudes are too large for the f32 filter (it could overflow to inf/NaN);
-// the slot then takes the exact sweep.  Below the limit every filter operation stays finite, so the
-// sign-bit test of the sweep is exact: D >= 0 <=> sign bit clear.
-__device__ __forceinline__ bool filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
+__device__ __forceinline__ void filter_pass_all(FilterParams &f)  // D = 1e30 - w >= 0: every record is a candidate
+{
+    f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
+    f.nppE = 1.0e30f;
+}
+
+// Magnitudes outside 1e-12 < M < 1e14 could overflow/underflow the f32 products: such a ray gets the
+// pass-all filter (its queue overflows and the slot takes the exact f64 sweep).  Inside the range every
+// filter operation stays finite, so the sweep's sign-bit test is exact: D >= 0 <=> sign bit clear.
+__device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
 {
     // centre the origin (better conditioned f32 products); all in f64, then one rounding each
     double px = pos.x - sv.sphere_center[0];
@@ -141,15 +154,14 @@ __device__ __forceinline__ bool filter_from_ray(const SceneView &sv, V3 pos, V3 
     double pz = pos.z - sv.sphere_center[2];
     double pp = px * px + py * py + pz * pz;
     double pd = px * dir.x + py * dir.y + pz * dir.z;
-    // error bound: |D_f32 - D| <= 64 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md "filter bound")
+    // error bound: |D_f32 - D| <= 24 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md 3.1); E = 64 * 2^-24 * M^2
     double M = sv.sphere_cmax + sqrt(pp);
-    if (!(M < 1.0e14) || !(M > 1.0e-12)) { filter_idle(f); return false; }   // no overflow, E stays a normal f32
+    if (!(M < 1.0e14) || !(M > 1.0e-12)) { filter_pass_all(f); return; }
     double E = M * M * (64.0 / 16777216.0);
     f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
     f.npd = (float)(-pd);
     f.p2x = (float)(2.0 * px); f.p2y = (float)(2.0 * py); f.p2z = (float)(2.0 * pz);
     f.nppE = (float)(E - pp);
-    return true;
 }
 
 // D for the two spheres of one LDS pair record
@@ -165,34 +177,44 @@ __device__ __forceinline__ f32x2 filter_disc2(const float4 A, const float4 B, co
     return __builtin_elementwise_fma(b, b, q - w);
 }
 
-template <int S, int THREADS, int CHUNK, int Q>
-__global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, RowsView rv, double *__restrict__ samples,
-                                                              double *__restrict__ state, Counters *__restrict__ ctr,
+// Per-slot data that lives between rounds, structure-of-arrays in HBM (slot = lane_gid + s * n_lanes):
+//   state  [12][n_slots] f64   ray.position, ray.direction, resulting_color, light_color  (ray.rs:4-21)
+//   fstate [ 8][n_slots] f32   the slot's filter parameters
+//   istate [ 3][n_slots] u32   local pixel, batch-local sample, bounce count
+// Only a one-bit-per-slot `live` mask stays in registers across rounds, so the heavy f64 code (primary ray
+// generation, exact tests, shading) exists once and loops over the slots instead of being unrolled S times.
+constexpr size_t kSlotBytes = 12 * sizeof(double) + 8 * sizeof(float) + 3 * sizeof(uint32_t);
+
+template <int S, int THREADS, int CHUNK, int Q, int WAVES_PER_EU>
+__global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(const SceneView *__restrict__ svp,
+                                                              const RowsView *__restrict__ rvp, double *__restrict__ samples,
+                                                              char *__restrict__ slot_mem, Counters *__restrict__ ctr,
                                                               unsigned long long *__restrict__ work_counter,
                                                               uint32_t verify, unsigned long long max_rounds)
 {
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
     constexpr int WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *lds_sph = reinterpret_cast<float4 *>(smem);                                  // [CHUNK]
     uint32_t *lds_q = reinterpret_cast<uint32_t *>(smem + (size_t)CHUNK * 16);           // [Q][S][THREADS]
-    uint32_t *lds_misc = lds_q + (size_t)Q * S * THREADS;                                // [WAVES + 4]
+    uint32_t *lds_cnt = lds_q + (size_t)Q * S * THREADS;                                 // [S][THREADS]
+    uint32_t *lds_misc = lds_cnt + (size_t)S * THREADS;                                  // [WAVES + 4]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
-    const uint64_t n_lanes = (uint64_t)gridDim.x * THREADS;         // SoA stride between slots of one lane
-    const uint64_t n_slots = n_lanes * S;                           // SoA stride between state fields
+    const uint64_t n_lanes = (uint64_t)gridDim.x * THREADS;         // SoA stride between the slots of one lane
+    const uint64_t n_slots = n_lanes * S;                           // SoA stride between fields
     const uint64_t lane_gid = (uint64_t)blockIdx.x * THREADS + tid;
+    double *state = reinterpret_cast<double *>(slot_mem);
+    float *fstate = reinterpret_cast<float *>(state + 12 * n_slots);
+    uint32_t *istate = reinterpret_cast<uint32_t *>(fstate + 8 * n_slots);
     const uint32_t ns = sv.n_spheres;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
-    uint32_t pl[S], smp[S], bnc[S], cnt[S];
-    bool force_exact[S];
-    FilterParams fp[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) { pl[s] = kInvalid; smp[s] = 0; bnc[s] = 0; cnt[s] = 0; force_exact[s] = false; filter_idle(fp[s]); }
-
-    unsigned long long segs = 0, exact = 0, filt = 0, mism = 0;
+    uint32_t live = 0;                           // bit s: slot s holds a ray
+    unsigned long long segs = 0, exact = 0, mism = 0, rounds_swept = 0;
 
     // Every round either advances every live ray by one segment or finds the queue drained, so a
     // workgroup needs at most (rays / slots + 2) * (max_bounces + 1) rounds; max_rounds is that bound
@@ -203,13 +225,9 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
             break;
         }
         // ---- refill idle slots from the global ray queue: ballot + prefix sum, one atomic per workgroup
-        unsigned long long idle_mask[S];
         uint32_t wave_need = 0;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            idle_mask[s] = __ballot(pl[s] == kInvalid);
-            wave_need += (uint32_t)__popcll(idle_mask[s]);
-        }
+        for (int s = 0; s < S; ++s) wave_need += (uint32_t)__popcll(__ballot(((live >> s) & 1u) == 0u));
         if (lane == 0) lds_misc[wave] = wave_need;
         __syncthreads();
         if (tid == 0) {
@@ -226,46 +244,61 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
         {
             unsigned long long base = ((unsigned long long)lds_misc[WAVES + 1] << 32) | lds_misc[WAVES];
             for (uint32_t w = 0; w < wave; ++w) base += lds_misc[w];
-#pragma unroll
+#pragma unroll 1
             for (int s = 0; s < S; ++s) {
-                if (pl[s] == kInvalid) {
-                    unsigned long long my = base + mbcnt(idle_mask[s]);
+                const bool idle = ((live >> s) & 1u) == 0u;
+                const unsigned long long m = __ballot(idle);          // same value as in the count above: bit s unchanged so far
+                if (idle) {
+                    const unsigned long long my = base + mbcnt(m);
                     if (my < rv.n_rays) {
                         uint32_t p, sl;
                         ray_index_to_pixel(rv, my, p, sl);
                         RayState r;
                         gen_primary(sv, rv, p, rv.sample_begin + sl, r);
-                        pl[s] = p; smp[s] = sl; bnc[s] = 0;
                         if (sv.n_objects == 0) {                                  // scene.rs:224-226
                             double *o = samples + ((uint64_t)sl * rv.npix + p) * 3;
                             o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
-                            pl[s] = kInvalid;
                         } else {
-                            double *st = state + (lane_gid + (uint64_t)s * n_lanes);
+                            const uint64_t slot = lane_gid + (uint64_t)s * n_lanes;
+                            double *st = state + slot;
                             st[0 * n_slots] = r.pos.x; st[1 * n_slots] = r.pos.y; st[2 * n_slots] = r.pos.z;
                             st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
                             st[6 * n_slots] = 0.0; st[7 * n_slots] = 0.0; st[8 * n_slots] = 0.0;
                             st[9 * n_slots] = 1.0; st[10 * n_slots] = 1.0; st[11 * n_slots] = 1.0;
-                            force_exact[s] = !filter_from_ray(sv, r.pos, r.dir, fp[s]);
+                            FilterParams f;
+                            filter_from_ray(sv, r.pos, r.dir, f);
+                            float *fs = fstate + slot;
+                            fs[0 * n_slots] = f.dx; fs[1 * n_slots] = f.dy; fs[2 * n_slots] = f.dz; fs[3 * n_slots] = f.npd;
+                            fs[4 * n_slots] = f.p2x; fs[5 * n_slots] = f.p2y; fs[6 * n_slots] = f.p2z; fs[7 * n_slots] = f.nppE;
+                            uint32_t *is = istate + slot;
+                            is[0 * n_slots] = p; is[1 * n_slots] = sl; is[2 * n_slots] = 0u;
+                            live |= 1u << s;
                         }
                     }
                 }
-                base += (unsigned long long)__popcll(idle_mask[s]);
+                base += (unsigned long long)__popcll(m);
             }
         }
         // ---- workgroup-uniform exit: nothing live here and the queue handed out nothing
-        bool live = false;
-#pragma unroll
-        for (int s = 0; s < S; ++s) live |= (pl[s] != kInvalid);
-        if (__ballot(live) != 0ull && lane == 0) lds_misc[WAVES + 2] = 1;
+        if (__ballot(live != 0u) != 0ull && lane == 0) lds_misc[WAVES + 2] = 1;
         __syncthreads();
         // the flag is cleared by thread 0 between the two refill barriers of the NEXT round, i.e. after
         // every wave has passed this read
         if (lds_misc[WAVES + 2] == 0) break;
 
         // ---- sweep the sphere list through LDS with the f32 filter
+        FilterParams fp[S];
+        uint32_t cnt[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) cnt[s] = force_exact[s] ? (uint32_t)Q + 1u : 0u;
+        for (int s = 0; s < S; ++s) {
+            cnt[s] = 0;
+            filter_idle(fp[s]);
+            if ((live >> s) & 1u) {
+                const float *fs = fstate + (lane_gid + (uint64_t)s * n_lanes);
+                fp[s].dx = fs[0 * n_slots]; fp[s].dy = fs[1 * n_slots]; fp[s].dz = fs[2 * n_slots]; fp[s].npd = fs[3 * n_slots];
+                fp[s].p2x = fs[4 * n_slots]; fp[s].p2y = fs[5 * n_slots]; fp[s].p2z = fs[6 * n_slots]; fp[s].nppE = fs[7 * n_slots];
+            }
+        }
         for (uint32_t c0 = 0; c0 < ns; c0 += CHUNK) {
             const uint32_t n = (ns - c0 < (uint32_t)CHUNK) ? ns - c0 : (uint32_t)CHUNK;
             const uint32_t n4 = (n + 3u) & ~3u;            // the device array is padded to a multiple of 4
@@ -299,76 +332,89 @@ __global__ __launch_bounds__(THREADS, 4) void trace_mixed_kernel(SceneView sv, R
                 }
             }
         }
-        filt += (unsigned long long)ns * S;        // counted per slot below would be exact; idle slots sweep too
-
-        // ---- exact f64 re-evaluation of the candidates, other shapes, shading
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (pl[s] != kInvalid) {
-                double *st = state + (lane_gid + (uint64_t)s * n_lanes);
-                RayState r;
-                r.pos = mk(st[0 * n_slots], st[1 * n_slots], st[2 * n_slots]);
-                r.dir = mk(st[3 * n_slots], st[4 * n_slots], st[5 * n_slots]);
-                const RayX rx = make_rayx(r.pos, r.dir);
-                Hit h;
-                hit_init(h);
-                ++segs;
-                if (cnt[s] > (uint32_t)Q) {
-                    // more candidates than the queue holds (many spheres along one line): exact sweep
-                    closest_spheres_exact(sv, rx, h);
-                    exact += ns;
-                } else {
-                    for (uint32_t k = 0; k < cnt[s]; ++k) {
-                        uint32_t idx = lds_q[((size_t)k * S + s) * THREADS + tid];
-                        if (idx < ns) {
-                            double t;
-                            if (sphere_distance(sv.spheres[idx], rx, &t)) hit_consider(h, t, sv.sphere_id[idx], 0, idx);
-                        }
-                    }
-                    exact += cnt[s];
-                    if (verify) {            // debug: the filter must never lose the exact winner
-                        Hit hv;
-                        hit_init(hv);
-                        closest_spheres_exact(sv, rx, hv);
-                        if (hv.id != h.id || (hv.id != kInvalid && hv.t != h.t)) ++mism;
-                    }
-                }
-                closest_planes_exact(sv, rx, h);
-                closest_tris_exact(sv, rx, h);
-                exact += sv.n_planes + sv.n_tris;
+        for (int s = 0; s < S; ++s) lds_cnt[s * THREADS + tid] = cnt[s];
+        rounds_swept += 1;
 
-                r.result = mk(st[6 * n_slots], st[7 * n_slots], st[8 * n_slots]);
-                bool done = true;
-                if (h.id != kInvalid) {                                            // scene.rs:233-236
-                    r.light = mk(st[9 * n_slots], st[10 * n_slots], st[11 * n_slots]);
-                    uint32_t k = pl[s] / rv.width;
-                    uint32_t x = pl[s] - k * rv.width;
-                    uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
-                    r.key = rng_key(sv.seed, pix, rv.sample_begin + smp[s]);
-                    r.draw = 6u + 2u * bnc[s];
-                    r.bounce = bnc[s];
-                    advance_and_shade(sv, h, r);
-                    bnc[s] = r.bounce;
-                    done = (r.bounce >= bounce_limit) || light_is_zero(r);         // scene.rs:227-228
-                    if (!done) {
-                        st[0 * n_slots] = r.pos.x; st[1 * n_slots] = r.pos.y; st[2 * n_slots] = r.pos.z;
-                        st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
-                        st[6 * n_slots] = r.result.x; st[7 * n_slots] = r.result.y; st[8 * n_slots] = r.result.z;
-                        st[9 * n_slots] = r.light.x; st[10 * n_slots] = r.light.y; st[11 * n_slots] = r.light.z;
-                        force_exact[s] = !filter_from_ray(sv, r.pos, r.dir, fp[s]);
+        // ---- exact f64 re-evaluation of the candidates, other shapes, shading (one code instance, loop over slots)
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            if (((live >> s) & 1u) == 0u) continue;
+            const uint64_t slot = lane_gid + (uint64_t)s * n_lanes;
+            double *st = state + slot;
+            uint32_t *is = istate + slot;
+            const uint32_t pl = is[0 * n_slots], smp = is[1 * n_slots], bnc = is[2 * n_slots];
+            const uint32_t ncand = lds_cnt[s * THREADS + tid];
+            RayState r;
+            r.pos = mk(st[0 * n_slots], st[1 * n_slots], st[2 * n_slots]);
+            r.dir = mk(st[3 * n_slots], st[4 * n_slots], st[5 * n_slots]);
+            const RayX rx = make_rayx(r.pos, r.dir);
+            Hit h;
+            hit_init(h);
+            ++segs;
+            if (ncand > (uint32_t)Q) {
+                // more candidates than the queue holds (many spheres along one line, or a pass-all filter): exact sweep
+                closest_spheres_exact(sv, rx, h);
+                exact += ns;
+            } else {
+                for (uint32_t k = 0; k < ncand; ++k) {
+                    const uint32_t idx = lds_q[((size_t)k * S + s) * THREADS + tid];
+                    if (idx < ns) {
+                        double t;
+                        if (sphere_distance(sv.spheres[idx], rx, &t)) hit_consider(h, t, sv.sphere_id[idx], 0, idx);
                     }
                 }
-                if (done) {
-                    double *o = samples + ((uint64_t)smp[s] * rv.npix + pl[s]) * 3;
-                    o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
-                    pl[s] = kInvalid;
-                    force_exact[s] = false;
-                    filter_idle(fp[s]);
+                exact += ncand;
+                if (verify) {            // debug: the filter must never lose the exact winner
+                    Hit hv;
+                    hit_init(hv);
+                    closest_spheres_exact(sv, rx, hv);
+                    if (hv.id != h.id || (hv.id != kInvalid && hv.t != h.t)) {
+                        ++mism;
+                        if (verify > 1 && mism < 3)
+                            printf("MISMATCH round %llu bnc %u pl %u blk %u tid %u s %d ncand %u h(%u,%g) hv(%u,%g) pos(%g,%g,%g) "
+                                   "dir(%g,%g,%g)\n", round, bnc, pl, blockIdx.x, tid, s, ncand, h.id, h.t, hv.id, hv.t, r.pos.x,
+                                   r.pos.y, r.pos.z, r.dir.x, r.dir.y, r.dir.z);
+                    }
                 }
+            }
+            closest_planes_exact(sv, rx, h);
+            closest_tris_exact(sv, rx, h);
+            exact += sv.n_planes + sv.n_tris;
+
+            r.result = mk(st[6 * n_slots], st[7 * n_slots], st[8 * n_slots]);
+            bool done = true;
+            if (h.id != kInvalid) {                                            // scene.rs:233-236
+                r.light = mk(st[9 * n_slots], st[10 * n_slots], st[11 * n_slots]);
+                const uint32_t k = pl / rv.width;
+                const uint32_t x = pl - k * rv.width;
+                const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
+                r.draw = 6u + 2u * bnc;
+                r.bounce = bnc;
+                advance_and_shade(sv, h, r);
+                done = (r.bounce >= bounce_limit) || light_is_zero(r);         // scene.rs:227-228
+                if (!done) {
+                    st[0 * n_slots] = r.pos.x; st[1 * n_slots] = r.pos.y; st[2 * n_slots] = r.pos.z;
+                    st[3 * n_slots] = r.dir.x; st[4 * n_slots] = r.dir.y; st[5 * n_slots] = r.dir.z;
+                    st[6 * n_slots] = r.result.x; st[7 * n_slots] = r.result.y; st[8 * n_slots] = r.result.z;
+                    st[9 * n_slots] = r.light.x; st[10 * n_slots] = r.light.y; st[11 * n_slots] = r.light.z;
+                    is[2 * n_slots] = r.bounce;
+                    FilterParams f;
+                    filter_from_ray(sv, r.pos, r.dir, f);
+                    float *fs = fstate + slot;
+                    fs[0 * n_slots] = f.dx; fs[1 * n_slots] = f.dy; fs[2 * n_slots] = f.dz; fs[3 * n_slots] = f.npd;
+                    fs[4 * n_slots] = f.p2x; fs[5 * n_slots] = f.p2y; fs[6 * n_slots] = f.p2z; fs[7 * n_slots] = f.nppE;
+                }
+            }
+            if (done) {
+                double *o = samples + ((uint64_t)smp * rv.npix + pl) * 3;
+                o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+                live &= ~(1u << s);
             }
         }
     }
-    flush_counters(ctr, segs, exact, filt);
+    flush_counters(ctr, segs, exact, rounds_swept * ns * S);
     if (verify) {
         mism = wave_sum_u64(mism);
         if (lane == 0 && mism) atomicAdd(&ctr[0].pad_, mism);
@@ -442,14 +488,14 @@ __global__ void debug_math_kernel(int op, const double *a, const double *b, doub
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_trace_exact(const SceneView &sv, const RowsView &rv, double *samples, Counters *counters,
-                              hipStream_t stream)
+hipError_t launch_trace_exact(const SceneView *d_sv, const RowsView *d_rv, const RowsView &rv, double *samples,
+                              Counters *counters, hipStream_t stream)
 {
     const uint64_t per_launch = 1ull << 30;                 // rays per launch (grid.x stays < 2^31)
     for (uint64_t off = 0; off < rv.n_rays; off += per_launch) {
         uint64_t n = rv.n_rays - off < per_launch ? rv.n_rays - off : per_launch;
         uint32_t blocks = (uint32_t)((n + 255) / 256);
-        hipLaunchKernelGGL(trace_exact_kernel, dim3(blocks), dim3(256), 0, stream, sv, rv, samples, counters, off);
+        hipLaunchKernelGGL(trace_exact_kernel, dim3(blocks), dim3(256), 0, stream, d_sv, d_rv, samples, counters, off);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -457,35 +503,77 @@ hipError_t launch_trace_exact(const SceneView &sv, const RowsView &rv, double *s
 }
 
 namespace {
-constexpr int kMixS = 2, kMixThreads = 512, kMixChunk = 2048, kMixQ = 8;
-constexpr size_t kMixLds = (size_t)kMixChunk * 16 + (size_t)kMixQ * kMixS * kMixThreads * 4 + (kMixThreads / 64 + 4) * 4;
+
+// Launch shapes of the MIXED kernel.  Variant 0 is the production shape; the others exist for tuning
+// runs (RTX_HIP_MIXED_VARIANT=n) and are kept compiled so that A/B timings come from one binary
+// (C2, 64 spp, one MI355X: variant 0 280 Mrays/s, variant 1 257).
+struct MixVariant {
+    int s, threads, chunk, q, blocks_per_cu;
+    size_t lds;
+    const void *fn;
+};
+
+template <int S, int T, int CH, int Q, int WPE, int BPC>
+MixVariant make_variant()
+{
+    MixVariant v;
+    v.s = S; v.threads = T; v.chunk = CH; v.q = Q; v.blocks_per_cu = BPC;
+    v.lds = (size_t)CH * 16 + (size_t)Q * S * T * 4 + (size_t)S * T * 4 + (T / 64 + 4) * 4;
+    v.fn = reinterpret_cast<const void *>(&trace_mixed_kernel<S, T, CH, Q, WPE>);
+    return v;
+}
+
+const MixVariant &mix_variant()
+{
+    static const MixVariant table[] = {
+        make_variant<2, 256, 1024, 8, 4, 4>(),      // 0: production: 4 workgroups x 4 waves per CU, 128 VGPRs, 34 KB LDS each
+        make_variant<2, 512, 2048, 8, 4, 2>(),      // 1: 2 workgroups x 8 waves per CU
+        make_variant<3, 256, 1024, 8, 3, 3>(),      // 2: 3 slots per lane, 12 waves/CU
+        make_variant<4, 256, 2048, 8, 2, 2>(),      // 3: 4 slots per lane, 8 waves/CU, 256 VGPRs
+        make_variant<1, 512, 1024, 8, 8, 4>(),      // 4: 1 slot per lane, 32 waves/CU
+        make_variant<2, 1024, 2048, 8, 4, 1>(),     // 5: one 1024-thread workgroup per CU
+        make_variant<4, 256, 2048, 8, 4, 2>(),      // 6: as 3, 128 VGPRs
+        make_variant<2, 256, 2048, 8, 4, 3>(),      // 7: as 0 with 2048-record chunks, 3 workgroups per CU
+        make_variant<2, 128, 1024, 8, 4, 8>(),      // 8: 128-thread workgroups
+    };
+    static const int idx = [] {
+        const char *e = getenv("RTX_HIP_MIXED_VARIANT");
+        int i = e ? atoi(e) : 0;
+        return (i < 0 || i >= (int)(sizeof(table) / sizeof(table[0]))) ? 0 : i;
+    }();
+    return table[idx];
+}
+
 }  // namespace
 
 size_t mixed_state_bytes(int n_cus)
 {
-    return (size_t)n_cus * 2 /*blocks per CU*/ * kMixThreads * kMixS * 12 * sizeof(double);
+    const MixVariant &v = mix_variant();
+    return (size_t)n_cus * v.blocks_per_cu * v.threads * v.s * kSlotBytes;
 }
 
-hipError_t launch_trace_mixed(const SceneView &sv, const RowsView &rv, double *samples, double *state, Counters *counters,
-                              unsigned long long *work_counter, int n_cus, bool verify, hipStream_t stream)
+hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                              double *samples, double *state, Counters *counters, unsigned long long *work_counter,
+                              int n_cus, bool verify, hipStream_t stream)
 {
-    auto kern = trace_mixed_kernel<kMixS, kMixThreads, kMixChunk, kMixQ>;
+    const MixVariant &v = mix_variant();
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMixLds);
+        hipError_t e = hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    uint64_t want = (rv.n_rays + (uint64_t)kMixThreads * kMixS - 1) / ((uint64_t)kMixThreads * kMixS);
-    uint64_t cap = (uint64_t)n_cus * 2;
+    const uint64_t slots_per_block = (uint64_t)v.threads * v.s;
+    uint64_t want = (rv.n_rays + slots_per_block - 1) / slots_per_block;
+    uint64_t cap = (uint64_t)n_cus * v.blocks_per_cu;
     uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
     const unsigned long long limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0ull : sv.max_bounces + 1ull;
-    const unsigned long long max_rounds = (rv.n_rays / ((uint64_t)kMixThreads * kMixS) + 2ull) * limit + 4ull;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kMixThreads), kMixLds, stream, sv, rv, samples, state, counters,
-                       work_counter, verify ? 1u : 0u, max_rounds);
-    return hipGetLastError();
+    unsigned long long max_rounds = (rv.n_rays / slots_per_block + 2ull) * limit + 4ull;
+    uint32_t verify_u = verify ? (getenv("RTX_HIP_DEBUG_PRINT") ? 2u : 1u) : 0u;
+    void *args[] = { (void *)&d_sv, (void *)&d_rv, (void *)&samples, (void *)&state, (void *)&counters, (void *)&work_counter,
+                     (void *)&verify_u, (void *)&max_rounds };
+    return hipLaunchKernel(v.fn, dim3(blocks), dim3(v.threads), args, v.lds, stream);
 }
 
 hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,

@@ -6,17 +6,18 @@
 namespace rtx {
 
 // samples: [n_samples][npix][3] doubles (one RGB per ray), written by the trace kernels.
-hipError_t launch_trace_exact(const SceneView &sv, const RowsView &rv, double *samples, Counters *counters,
-                              hipStream_t stream);
+// d_sv / d_rv: device copies of the scene and launch descriptors (sv / rv are the host originals).
+hipError_t launch_trace_exact(const SceneView *d_sv, const RowsView *d_rv, const RowsView &rv, double *samples,
+                              Counters *counters, hipStream_t stream);
 
 // MIXED kernel: persistent workgroups, f32 sphere filter staged through LDS, exact f64 re-test of
 // candidates.  work_counter: one zeroed u64 on the device (ray queue head).
 // state: mixed_state_bytes(n_cus) bytes of device scratch (SoA ray state).  verify: also run the exact
 // sweep per segment and count disagreements into counters[0].pad_ (debug).
 size_t mixed_state_bytes(int n_cus);
-hipError_t launch_trace_mixed(const SceneView &sv, const RowsView &rv, double *samples, double *state,
-                              Counters *counters, unsigned long long *work_counter, int n_cus, bool verify,
-                              hipStream_t stream);
+hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                              double *samples, double *state, Counters *counters, unsigned long long *work_counter,
+                              int n_cus, bool verify, hipStream_t stream);
 
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
 // sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.

@@ -14,11 +14,11 @@ for name, objs, w, h, spp in cases:
     if name not in which: continue
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, rays_per_pixel=spp)
     print(name, "oracle segments", int(seg.sum()), "mean", ref.mean(), flush=True)
-    for kern in (rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_MIXED_VERIFY):
+    for kern in [int(k) for k in os.environ.get('KERNELS', '1,2,3').split(',')]:
         t0 = time.time()
         try:
             img = hip_render(rtx, objs, w, h, kernel=kern, rays_per_pixel=spp)
         except Exception as e:
             print(name, "kernel", kern, "FAILED", e, flush=True); continue
         dt = time.time() - t0
-        print(name, "kernel", kern, "maxdiff", max_abs_diff(img, ref), "bit-identical pixels", int((img == ref).all(axis=2).sum()), "/", w*h, "mean", img.mean(), "t=%.3f" % dt, flush=True)
+        print(name, "kernel", kern, "maxdiff", max_abs_diff(img, ref), "bit-identical pixels", int((img == ref).all(axis=2).sum()), "/", w*h, "mean", img.mean(), "nonzero px", int((img != 0).any(axis=2).sum()), "t=%.3f" % dt, flush=True)
