@@ -47,8 +47,11 @@ enum {
     RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
     RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
                               produces the same bits as RTX_KERNEL_EXACT */
-    RTX_KERNEL_MIXED_VERIFY = 3 /* debug: MIXED that also runs the exact sweep per segment and counts
+    RTX_KERNEL_MIXED_VERIFY = 3, /* debug: MIXED that also runs the exact sweep per segment and counts
                               disagreements in RtxStats.filter_mismatches (must stay 0) */
+    RTX_KERNEL_BVH = 4     /* spheres found by traversal of a flat BVH built at upload, exact f64
+                              leaf tests; planes and triangles tested exhaustively; same bits as RTX_KERNEL_EXACT.
+                              RtxStats.filter_tests then counts BVH node visits */
 };
 
 /* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)

@@ -111,7 +111,7 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
 
 int32_t check_config(const RtxConfig &cfg)
 {
-    if (cfg.kernel > RTX_KERNEL_MIXED_VERIFY) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
+    if (cfg.kernel > RTX_KERNEL_BVH) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
     if (cfg.max_bounces == UINT64_MAX)       // max_bounces + 1 overflows in the reference (scene.rs:227)
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.max_bounces + 1 overflows");
     if (cfg.rays_per_pixel > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.rays_per_pixel exceeds 2^32-1");
@@ -273,7 +273,24 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
     h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
 
+    // flat BVH over the spheres (rtx_bvh.h); skipped for tiny or non-finite sphere sets and for trees deeper
+    // than the traversal stack (the BVH kernel then sweeps the spheres exhaustively)
+    BvhBuild bvh;
+    if (spheres.size() > (size_t)kBvhLeafSize) {
+        std::vector<double> s4(4 * spheres.size());
+        for (size_t k = 0; k < spheres.size(); ++k) {
+            const RtxObject &o = scene->objects[sphere_id[k]];
+            for (int c = 0; c < 4; ++c) s4[4 * k + c] = o.geom[c];
+        }
+        bvh = build_sphere_bvh(s4.data(), (uint32_t)spheres.size());
+        if (bvh.depth > kBvhMaxDepth) bvh = BvhBuild();
+    }
+    h->sv.n_bvh_nodes = (uint32_t)bvh.nodes.size();
+    h->sv.bvh_depth = (uint32_t)bvh.depth;
+
     int32_t rc = RTX_OK;
+    if (!rc) rc = upload_vec(h, bvh.nodes, &h->sv.bvh_nodes);
+    if (!rc) rc = upload_vec(h, bvh.prims, &h->sv.bvh_prims);
     if (!rc) rc = upload_vec(h, spheres, &h->sv.spheres);
     if (!rc) rc = upload_vec(h, sphere_id, &h->sv.sphere_id);
     if (!rc) rc = upload_vec(h, planes, &h->sv.planes);
@@ -372,7 +389,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (batch < spp) {
         if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
     }
-    if (kernel != RTX_KERNEL_EXACT) {
+    if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
 
@@ -404,6 +421,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
+        } else if (kernel == RTX_KERNEL_BVH) {
+            RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
+            RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter, h->n_cus, stream));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,

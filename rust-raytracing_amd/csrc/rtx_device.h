@@ -2,6 +2,7 @@
 // EXACT and MIXED trace kernels (primary-ray generation, shading, bounce direction).
 #pragma once
 
+#include "rtx_bvh.h"
 #include "rtx_scene.h"
 
 namespace rtx {
@@ -28,6 +29,11 @@ struct SceneView {
                                                // padded to a multiple of 4 spheres
     double          sphere_center[3];          // centre of the spheres' bounding box
     double          sphere_cmax;               // max over spheres of |c - centre| + r
+    // flat BVH over the spheres (rtx_bvh.h); null when the scene has none
+    const BvhNode  *bvh_nodes;
+    const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
+    uint32_t        n_bvh_nodes;
+    uint32_t        bvh_depth;
 };
 
 // Which pixels/samples one launch covers.

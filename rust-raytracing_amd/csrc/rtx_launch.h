@@ -19,6 +19,12 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
                               double *samples, double *state, Counters *counters, unsigned long long *work_counter,
                               int n_cus, bool verify, hipStream_t stream);
 
+// BVH kernel: persistent waves, one ray per lane, per-lane stack traversal of the flat sphere BVH with an f64
+// slab test; leaves and the other shapes use the exact f64 tests.  work_counter: zeroed u64 ray-queue head.
+hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                            double *samples, Counters *counters, unsigned long long *work_counter, int n_cus,
+                            hipStream_t stream);
+
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
 // sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.
 hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,

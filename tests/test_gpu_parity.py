@@ -32,7 +32,7 @@ def gpu(rtx):
 
 
 def _kernels(rtx):
-    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED]
+    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH]
 
 
 # ---- device arithmetic ---------------------------------------------------------------------------
@@ -73,7 +73,7 @@ def test_hip_matches_oracle_seeded(gpu, oracle, case):
         "tris": (scenes.light_every(scenes.compact(scenes.random_triangles(400, 5)), 3), 48, 32, dict(rays_per_pixel=3, seed=8)),
     }[case]
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
         scene = hip_scene(gpu, objs, kernel=kern, **cfg)
         img = scene.render(w, h)
         assert max_abs_diff(img, ref) <= ATOL, (case, kern)
@@ -89,16 +89,19 @@ def test_mixed_kernel_is_bit_identical_to_exact_kernel(gpu):
     w, h, spp = 320, 180, 4
     cam = gpu.Camera(*scenes.CAMERA)
     out = {}
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED_VERIFY):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
         hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, kernel=kern), cam, objs).upload(0)
         buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-        out[kern] = (buf.cpu().numpy(), st.segments, st.filter_mismatches)
+        out[kern] = (buf.cpu().numpy(), st.segments, st.filter_mismatches, st.exact_tests, st.filter_tests)
         hnd.close()
-    a, b = out[gpu.RTX_KERNEL_EXACT], out[gpu.RTX_KERNEL_MIXED_VERIFY]
+    a, b, c = out[gpu.RTX_KERNEL_EXACT], out[gpu.RTX_KERNEL_MIXED_VERIFY], out[gpu.RTX_KERNEL_BVH]
     assert np.array_equal(a[0], b[0])
     assert a[1] == b[1] and b[2] == 0
     assert a[0].mean() > 0.01
+    # the BVH kernel visits a tiny fraction of the 10^4 spheres per segment and still produces the same bits
+    assert np.array_equal(a[0], c[0]) and a[1] == c[1]
+    assert c[3] < a[3] / 50 and c[4] > 0
 
 
 # ---- properties that hold at any size --------------------------------------------------------------------
@@ -127,6 +130,24 @@ def test_tie_break_first_object_wins(gpu):
         assert hip_render(gpu, o[::-1].copy(), 16, 16, kernel=kern, **cfg)[8, 8].tolist() == [0.0, 1.0, 0.0]
 
 
+def test_many_identical_spheres_first_wins(gpu, oracle):
+    """24 copies of one sphere (all in one BVH leaf region, zero-extent centroid bounds) + 40 others: the copy that
+    comes first in Scene.objects must win every tie (scene.rs:250), whatever order the BVH visits them in."""
+    from rust_raytracing_amd import scenes
+    o = scenes.compact(scenes.random_spheres(64, 9))
+    o["base_color"] = 0.0
+    o["emission_color"] = np.round(np.random.default_rng(2).uniform(0.1, 2, size=(64, 3)) * 16) / 16
+    dup = np.arange(5, 64, 2)[:24]
+    o["geom"][dup] = (5.0, 0.0, 0.0, 1.5, 0, 0, 0, 0, 0)
+    cfg = dict(rays_per_pixel=2, focal_offset=0.0, non_focal_offset=0.0)
+    ref = oracle_render(oracle, o, 48, 32, **cfg)
+    assert ref[16, 24].tolist() == o[dup[0]]["emission_color"].tolist()
+    for kern in _kernels(gpu):
+        assert np.array_equal(hip_render(gpu, o, 48, 32, kernel=kern, **cfg), ref)
+        assert np.array_equal(hip_render(gpu, o[::-1].copy(), 48, 32, kernel=kern, **cfg),
+                              oracle_render(oracle, o[::-1].copy(), 48, 32, **cfg))
+
+
 def test_candidate_queue_overflow_falls_back_to_exact_sweep(gpu, oracle):
     """More spheres along one line of sight than the per-ray LDS queue holds (8): 40 concentric-ish shells."""
     from rust_raytracing_amd import scenes
@@ -141,7 +162,7 @@ def test_candidate_queue_overflow_falls_back_to_exact_sweep(gpu, oracle):
     o[3]["emission_color"] = (1, 0.5, 0.25)
     cfg = dict(rays_per_pixel=4, seed=11)
     ref = oracle_render(oracle, o, 48, 32, **cfg)
-    for kern in (gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY):
+    for kern in (gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
         assert max_abs_diff(hip_render(gpu, o, 48, 32, kernel=kern, **cfg), ref) <= ATOL
 
 
