@@ -6,19 +6,24 @@ Scene::render hot path on the 10k-sphere 1920x1080 scene (configs[1], "C2").
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A step = one full render of the frame: every rank traces its interleaved row band of the image with the
-MIXED HIP kernel (scene resident in HBM before the timed region), then ONE gather (RCCL over xGMI)
-brings the bands to rank 0.  Scaling is weak: the frame is fixed at 1920x1080 and rays_per_pixel = 64 * N,
-so every GPU traces the same number of primary rays (132.7 M) whatever N is.  value = all ranks' primary
-rays / (max-over-ranks time of the K steps).
+A step = one full render of the frame: every rank traces its interleaved row band of the image (scene resident
+in HBM before the timed region), then ONE gather (RCCL over xGMI) brings the bands to rank 0.  Scaling is weak:
+the frame is fixed at 1920x1080 and rays_per_pixel = 64 * N, so every GPU traces the same number of primary
+rays (132.7 M) whatever N is.  value = all ranks' primary rays / (max-over-ranks time of the K steps).
 
-The same JSON line carries
-  roofline      logical operand bandwidth of the trace kernel (segments x n_spheres x 16 B per launch, SURVEY
-                8d / DESIGN.md) / its average duration measured with hipEvents on the launch stream, against
-                the 8 TB/s HBM peak.  The list is LDS/L2-resident by design, so frac may exceed 1: the kernel is
-                VALU-bound, and valu_frac gives the fraction of the VALU issue ceiling beside it.
-  cpu_baseline  the CPU oracle (a C restatement of the reference's CPU path: kind "port"; the Rust crate cannot
-                be built here) timed on this host's cores on a bounded sample of the same scene.
+Kernels (all produce the same bits; tests/test_gpu_parity.py):
+  --kernel 0  AUTO (default) = the flat-BVH kernel for this scene          -> `value`, `roofline`
+  --kernel 2  the LDS-staged f32-filter sweep named in BASELINE.json configs[1]; at N=1 it is ALSO timed after the
+              main measurement and reported as `lds_sweep` (own roofline), so both designs are on record
+  --kernel 1  exact f64 sweep (parity kernel)
+
+roofline (dominant kernel = the trace kernel of rank 0): algorithmic bytes per launch / average launch duration
+measured with hipEvents on the launch stream, against the 8 TB/s HBM peak.
+  BVH kernel:   bytes = box_tests*32 + leaf_filter_tests*16 + exact_tests*32 + hits*56  (all counted by the kernel)
+  LDS sweep:    bytes = segments * n_spheres * 16.  The list is LDS/L2-resident by design, so frac may
+                exceed 1: that kernel is VALU-bound, and valu_frac gives the fraction of the VALU issue ceiling.
+cpu_baseline: the CPU oracle (a C restatement of the reference's CPU path: kind "port"; the Rust crate cannot be
+built here) timed on this host's cores on a bounded sample of the same scene.
 """
 import argparse
 import json
@@ -36,7 +41,9 @@ import torch.distributed as dist   # noqa: E402
 WIDTH, HEIGHT, SPP_PER_GPU, N_SPHERES = 1920, 1080, 64, 10000
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9      # 256 CU x 4 SIMD-32 x 2.4 GHz
-FILTER_OPS_PER_TEST = 9.0          # VALU instructions of the f32 sphere filter per (ray, sphere)
+FILTER_OPS_PER_TEST = 8.0          # lane-ops of the f32 sphere filter per (ray, sphere): 7 fma + 1 add
+KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 filter sweep + exact f64 (trace_mixed_kernel)",
+                3: "trace_mixed_kernel + verify", 4: "flat 4-wide BVH + f32 filter + exact f64 (trace_bvh_kernel)"}
 
 
 def parse():
@@ -45,8 +52,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=None, help="rays per pixel per GPU (default 64: the named config)")
-    ap.add_argument("--kernel", type=int, default=2, help="1 exact f64, 2 mixed (default)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lds-sweep", action="store_true", help="skip the secondary measurement of the LDS sweep kernel")
     ap.add_argument("--cpu-sample", default="240x135x1", help="WxHxSPP sample of the same scene for the CPU leg")
     return ap.parse_args()
 
@@ -81,6 +89,58 @@ def cpu_baseline(sample):
         "clean_Mrays_s": out["clean"][0], "faithful_Mrays_s": out["faithful"][0],
         "Msegments_s": out[best][1], "seconds": out["clean"][2] + out["faithful"][2],
     }
+
+
+class Acc:
+    """Sums RtxStats over the timed steps."""
+
+    def __init__(self):
+        self.trace_ms = 0.0
+        self.segments = self.filter = self.exact = self.box = 0
+        self.kernel = 0
+        self.n = 0
+
+    def add(self, st):
+        self.trace_ms += st.trace_ms
+        self.segments += st.segments
+        self.filter += st.filter_tests
+        self.exact += st.exact_tests
+        self.box += st.box_tests
+        self.kernel = st.kernel
+        self.n += 1
+
+
+def roofline_of(acc, traffic_key):
+    steps = max(acc.n, 1)
+    avg_ms = acc.trace_ms / steps
+    seg = acc.segments / steps
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": KERNEL_NAMES.get(acc.kernel, str(acc.kernel)),
+           "avg_launch_ms": avg_ms, "segments_per_launch": seg}
+    if acc.kernel == 4:
+        box, leaf, exact = acc.box / steps, (acc.filter - acc.box) / steps, acc.exact / steps
+        nbytes = box * 32.0 + leaf * 16.0 + exact * 32.0
+        out.update({"algorithmic_bytes_per_segment": nbytes / seg if seg else 0.0,
+                    "box_tests_per_segment": box / seg if seg else 0.0, "leaf_filter_tests_per_segment": leaf / seg if seg else 0.0,
+                    "exact_tests_per_segment": exact / seg if seg else 0.0,
+                    "note": "traversal bytes counted by the kernel (32 B per box test, 16 B per leaf filter record, 32 B per exact "
+                            "sphere test); node fetches are dependent L2/HBM reads: latency- and issue-bound, not bandwidth-bound"})
+    else:
+        nbytes = seg * N_SPHERES * 16.0
+        out.update({"algorithmic_bytes_per_segment": N_SPHERES * 16,
+                    "valu_frac": (acc.filter / steps * FILTER_OPS_PER_TEST) / (avg_ms * 1e-3) / VALU_LANE_OPS_PER_S
+                    if avg_ms > 0 and acc.filter else None,
+                    "note": "logical operand bandwidth (list is LDS/L2-resident by design; may exceed the HBM peak)"})
+    out["achieved"] = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out["frac"] = out["achieved"] / HBM_PEAK_GBS
+    out["traffic"] = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            rec = json.load(open(tj)).get(traffic_key)
+            out["traffic"] = rec["hbm_bytes_per_launch"] if rec else None
+        except Exception:
+            pass
+    return out
 
 
 def main():
@@ -123,58 +183,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    trace_ms, segments, filt, exact = 0.0, 0, 0, 0
-    full = None
-    for _ in range(args.steps):
-        st, full = step()
-        trace_ms += st.trace_ms
-        segments += st.segments
-        filt += st.filter_tests
-        exact += st.exact_tests
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        acc, full = Acc(), None
+        for _ in range(n_steps):
+            st, full = step()
+            acc.add(st)
+        fence()
+        return time.perf_counter() - t0, acc, full
+
+    elapsed, acc, full = timed(args.warmup, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed, trace_ms, float(segments)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(acc.segments)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-        total_segments = int(tsum[2])
+        total_segments = int(tsum[1])
     else:
-        total_segments = segments
+        total_segments = acc.segments
+
+    lds = None
+    if world == 1 and not args.no_lds_sweep and acc.kernel != 2 and args.steps > 0:
+        handle.set_config(cfg.with_kernel(rtx.RTX_KERNEL_MIXED))
+        e2, acc2, full2 = timed(1, 2)
+        lds = {"value": WIDTH * HEIGHT * spp * 2 / e2 / 1e6, "unit": "Mrays/s", "ms_per_step": e2 / 2 * 1e3,
+               "image_identical_to_value_kernel": bool(torch.equal(full, full2)) if full is not None else None,
+               "roofline": roofline_of(acc2, "c2_%dspp_kernel2" % spp_per_gpu)}
+        handle.set_config(cfg)
 
     if rank == 0:
         steps = max(args.steps, 1)
         rays_per_step = WIDTH * HEIGHT * spp
         value = rays_per_step * args.steps / elapsed / 1e6 if args.steps else 0.0
-        mean = float(full.mean()) if full is not None else float("nan")
-        # dominant kernel = trace kernel of THIS rank: algorithmic bytes per launch / average launch duration
-        seg_per_launch = segments / steps
-        bytes_per_launch = seg_per_launch * N_SPHERES * 16.0
-        avg_ms = trace_ms / steps
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                rec = json.load(open(tj)).get("c2_%dspp_kernel%d" % (spp_per_gpu, args.kernel))
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
-            except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "kernel": "trace_mixed_kernel" if args.kernel != 1 else "trace_exact_kernel",
-            "avg_launch_ms": avg_ms, "segments_per_launch": seg_per_launch,
-            "algorithmic_bytes_per_segment": N_SPHERES * 16,
-            "note": "logical operand bandwidth (list is LDS/L2-resident by design; may exceed the HBM peak)",
-            "valu_frac": (filt / steps * FILTER_OPS_PER_TEST) / (avg_ms * 1e-3) / VALU_LANE_OPS_PER_S if avg_ms > 0 and filt else None,
-        }
         line = {
             "metric": "Mrays/s (primary rays, whole node), 10k-sphere 1080p 64spp",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,12 +229,14 @@ def main():
                                    "max_bounces 10, render seed 42" % (spp_per_gpu, spp),
                        "width": WIDTH, "height": HEIGHT, "rays_per_pixel": spp, "n_spheres": N_SPHERES,
                        "partition": "interleaved row bands, 1 gather" if world > 1 else "single GPU",
-                       "kernel": "mixed (f32 LDS filter + exact f64)" if args.kernel != 1 else "exact f64"},
+                       "kernel": KERNEL_NAMES.get(acc.kernel, str(acc.kernel))},
             "Msegments_per_s": total_segments / elapsed / 1e6,
             "segments_per_primary_ray": total_segments / (rays_per_step * steps),
-            "image_mean": mean,
-            "roofline": roofline,
+            "image_mean": float(full.mean()) if full is not None else float("nan"),
+            "roofline": roofline_of(acc, "c2_%dspp_kernel%d" % (spp_per_gpu, acc.kernel)),
         }
+        if lds is not None:
+            line["lds_sweep"] = lds
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_sample)
             line["cpu_baseline"] = cb

@@ -43,7 +43,8 @@ enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_TRIANGLE = 2 };
 
 /* Kernel selection (RtxConfig.kernel). */
 enum {
-    RTX_KERNEL_AUTO  = 0,  /* = RTX_KERNEL_MIXED */
+    RTX_KERNEL_AUTO  = 0,  /* RTX_KERNEL_BVH when the scene has more than 4 (finite) spheres, else RTX_KERNEL_MIXED;
+                              all kernels produce the same bits, AUTO picks the fastest */
     RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
     RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
                               produces the same bits as RTX_KERNEL_EXACT */
@@ -107,8 +108,9 @@ typedef struct RtxStats {
     double   trace_ms;           /* device time of the trace kernel(s), hipEvent on the launch stream */
     double   resolve_ms;         /* device time of the per-pixel sample fold */
     uint64_t filter_mismatches;  /* RTX_KERNEL_MIXED_VERIFY only */
+    uint64_t box_tests;          /* RTX_KERNEL_BVH only: ray/box slab tests (32 B node each) */
     uint32_t trace_launches;
-    uint32_t reserved;
+    uint32_t kernel;             /* the RTX_KERNEL_* that ran (resolves RTX_KERNEL_AUTO) */
 } RtxStats;
 
 typedef struct RtxSceneHandle_ *RtxSceneHandle;

@@ -41,7 +41,8 @@ class RtxScene(C.Structure):
 class RtxStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("segments", C.c_uint64), ("exact_tests", C.c_uint64),
                 ("filter_tests", C.c_uint64), ("trace_ms", C.c_double), ("resolve_ms", C.c_double),
-                ("filter_mismatches", C.c_uint64), ("trace_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("filter_mismatches", C.c_uint64), ("box_tests", C.c_uint64),
+                ("trace_launches", C.c_uint32), ("kernel", C.c_uint32)]
 
 
 # every symbol include/rtx_hip.h declares: (name, restype, argtypes)

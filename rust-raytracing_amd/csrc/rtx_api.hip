@@ -283,14 +283,21 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
             for (int c = 0; c < 4; ++c) s4[4 * k + c] = o.geom[c];
         }
         bvh = build_sphere_bvh(s4.data(), (uint32_t)spheres.size());
-        if (bvh.depth > kBvhMaxDepth) bvh = BvhBuild();
     }
-    h->sv.n_bvh_nodes = (uint32_t)bvh.nodes.size();
-    h->sv.bvh_depth = (uint32_t)bvh.depth;
+    Bvh4Build bvh4 = collapse_to_bvh4(bvh);
+    h->sv.n_bvh_nodes = (uint32_t)bvh4.nodes.size();
+    h->sv.bvh_depth = (uint32_t)bvh4.depth;
+    h->sv.bvh_origin_limit = (float)bvh.origin_limit;
+    std::vector<float4> leaf32(bvh.prims.size());
+    for (size_t k = 0; k < bvh.prims.size(); ++k) {
+        const uint32_t p = bvh.prims[k];
+        leaf32[k] = make_float4(fx[p], fy[p], fz[p], fw[p]);
+    }
 
     int32_t rc = RTX_OK;
-    if (!rc) rc = upload_vec(h, bvh.nodes, &h->sv.bvh_nodes);
+    if (!rc) rc = upload_vec(h, bvh4.nodes, &h->sv.bvh_nodes);
     if (!rc) rc = upload_vec(h, bvh.prims, &h->sv.bvh_prims);
+    if (!rc) rc = upload_vec(h, leaf32, &h->sv.bvh_leaf_f32);
     if (!rc) rc = upload_vec(h, spheres, &h->sv.spheres);
     if (!rc) rc = upload_vec(h, sphere_id, &h->sv.sphere_id);
     if (!rc) rc = upload_vec(h, planes, &h->sv.planes);
@@ -339,7 +346,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     const uint32_t npix = n_rows * width;
     const uint64_t spp = h->cfg.rays_per_pixel;
-    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? RTX_KERNEL_MIXED : h->cfg.kernel;
+    // AUTO: the BVH kernel when a sphere BVH was built at upload (> 4 finite spheres), else the LDS sweep
+    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? (h->sv.n_bvh_nodes != 0 ? RTX_KERNEL_BVH : RTX_KERNEL_MIXED)
+                                                              : h->cfg.kernel;
 
     // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row
     const size_t tdbl = 2 * (size_t)width + 2 * (size_t)n_rows;
@@ -451,6 +460,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             stats->filter_tests += host[k].filter_tests;
         }
         stats->filter_mismatches = host[0].pad_;
+        for (int k = 2; k < kCounterShards; ++k) stats->box_tests += host[k].pad_;
         if (host[1].pad_ != 0)
             return fail(RTX_ERR_HIP, "trace kernel hit its round bound (internal error): " + std::to_string(host[1].pad_) +
                                          " workgroup(s) left early");
@@ -458,6 +468,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         stats->trace_ms = trace_ms;
         stats->resolve_ms = resolve_ms;
         stats->trace_launches = launches;
+        stats->kernel = kernel;                       // the kernel that actually ran (RTX_KERNEL_*)
     }
     return RTX_OK;
 }

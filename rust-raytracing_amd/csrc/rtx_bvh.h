@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -25,8 +26,9 @@ namespace rtx {
 // 32-byte node of the flat array (depth-first order: the left child of node i is node i + 1).
 //   interior: count == 0, link = index of the right child
 //   leaf:     count  > 0, link = first entry in bvh_prims[], count entries
-// Boxes are f32, rounded OUTWARD from the f64 sphere bounds and inflated, so that the f64 slab test of the
-// traversal (which converts them back to f64) can never exclude a sphere the exact test would accept.
+// Boxes are f32, rounded OUTWARD from the f64 sphere bounds and inflated (relative 2^-20 of the sphere's reach plus
+// BvhBuild::abs_pad), so that the f32 slab test of the traversal can never exclude a sphere the exact f64 test
+// would accept.
 struct BvhNode {
     float lo[3];
     uint32_t link;
@@ -42,6 +44,12 @@ struct BvhBuild {
     std::vector<BvhNode> nodes;
     std::vector<uint32_t> prims;          // local sphere indices, leaf-contiguous
     int depth = 0;
+    // The traversal's slab test runs in f32: t = fl(fl(b - fl(o)) * fl(1/d)).  Rounding the origin shifts both faces
+    // of an axis by at most 2^-24 |o|, every other rounding is a relative error <= 2^-22 on t (handled in the test).
+    // Every box is therefore also inflated by `abs_pad` >= 2^-22 * origin_limit on each side; rays whose origin lies
+    // outside |o|_inf <= origin_limit do not use the tree (they sweep the spheres exhaustively).
+    double origin_limit = 0.0;
+    double abs_pad = 0.0;
 };
 
 inline float round_down_f32(double x)
@@ -79,6 +87,12 @@ inline BvhBuild build_sphere_bvh(const double *spheres4, uint32_t n)
             cen[3 * (size_t)i + a] = s[a];
         }
     }
+    double scale = 0.0;
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(box[i].lo[a]), std::fabs(box[i].hi[a])));
+    out.origin_limit = 4.0 * scale + 1.0;
+    out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
+    if (!(out.origin_limit < 1.0e30)) return BvhBuild();
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     out.nodes.reserve(2 * (size_t)n / kBvhLeafSize + 2);
@@ -103,7 +117,10 @@ inline BvhBuild build_sphere_bvh(const double *spheres4, uint32_t n)
             }
         }
         BvhNode node;
-        for (int a = 0; a < 3; ++a) { node.lo[a] = round_down_f32(b.lo[a]); node.hi[a] = round_up_f32(b.hi[a]); }
+        for (int a = 0; a < 3; ++a) {
+            node.lo[a] = round_down_f32(b.lo[a] - out.abs_pad);
+            node.hi[a] = round_up_f32(b.hi[a] + out.abs_pad);
+        }
         const uint32_t cnt = t.end - t.begin;
         if (cnt <= (uint32_t)kBvhLeafSize) {
             node.link = (uint32_t)out.prims.size();
@@ -128,6 +145,85 @@ inline BvhBuild build_sphere_bvh(const double *spheres4, uint32_t n)
         // depth-first: the left child must be the next node emitted -> push right first
         todo.push_back({mid, t.end, (int)me, t.depth + 1});
         todo.push_back({t.begin, mid, -1, t.depth + 1});
+    }
+    return out;
+}
+
+// ---- 4-wide nodes -------------------------------------------------------------------------------------------
+// The traversal is bound by the latency of dependent node fetches, so the binary tree is collapsed into nodes
+// that hold the boxes of up to four children inline: one 128-byte fetch per step, half the depth.
+//   child c: A = {lo.xyz, link}, B = {hi.xyz, count}
+//     count == 0          interior child, link = index of its Bvh4Node
+//     1 <= count <= leaf  leaf child, link = first entry in prims[], count entries
+//     count == 0xFFFFFFFF empty slot (box inverted: never hit)
+struct Bvh4Node {
+    float4 a[4];
+    float4 b[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
+
+constexpr int kBvh4StackEntries = 24;     // per-ray traversal stack (LDS); deeper trees may overflow it (handled)
+
+struct Bvh4Build {
+    std::vector<Bvh4Node> nodes;
+    int depth = 0;
+};
+
+inline float u32_as_f32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
+{
+    Bvh4Build out;
+    if (b2.nodes.empty()) return out;
+    auto area = [&](uint32_t i) {
+        const BvhNode &n = b2.nodes[i];
+        const double dx = (double)n.hi[0] - n.lo[0], dy = (double)n.hi[1] - n.lo[1], dz = (double)n.hi[2] - n.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Task { uint32_t bin; uint32_t wide; int depth; };
+    std::vector<Task> todo;
+    out.nodes.emplace_back();
+    todo.push_back({0u, 0u, 1});
+    while (!todo.empty()) {
+        const Task t = todo.back();
+        todo.pop_back();
+        out.depth = std::max(out.depth, t.depth);
+        uint32_t kids[4];
+        int nk = 0;
+        if (b2.nodes[t.bin].count != 0) {
+            kids[nk++] = t.bin;                                   // a leaf root: one leaf child
+        } else {
+            kids[nk++] = t.bin + 1;
+            kids[nk++] = b2.nodes[t.bin].link;
+            while (nk < 4) {                                      // open the interior child with the largest box
+                int best = -1;
+                double best_area = -1.0;
+                for (int k = 0; k < nk; ++k)
+                    if (b2.nodes[kids[k]].count == 0 && area(kids[k]) > best_area) { best = k; best_area = area(kids[k]); }
+                if (best < 0) break;
+                const uint32_t open = kids[best];
+                kids[best] = open + 1;
+                kids[nk++] = b2.nodes[open].link;
+            }
+        }
+        Bvh4Node w;
+        for (int c = 0; c < 4; ++c) {
+            if (c < nk) {
+                const BvhNode &n = b2.nodes[kids[c]];
+                uint32_t link = n.link, count = n.count;
+                if (count == 0) {                                 // interior child: gets its own wide node
+                    link = (uint32_t)out.nodes.size();
+                    out.nodes.emplace_back();
+                    todo.push_back({kids[c], link, t.depth + 1});
+                }
+                w.a[c] = make_float4(n.lo[0], n.lo[1], n.lo[2], u32_as_f32(link));
+                w.b[c] = make_float4(n.hi[0], n.hi[1], n.hi[2], u32_as_f32(count));
+            } else {
+                w.a[c] = make_float4(INFINITY, INFINITY, INFINITY, u32_as_f32(0u));
+                w.b[c] = make_float4(-INFINITY, -INFINITY, -INFINITY, u32_as_f32(0xFFFFFFFFu));
+            }
+        }
+        out.nodes[t.wide] = w;
     }
     return out;
 }

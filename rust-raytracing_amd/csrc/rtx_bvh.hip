@@ -3,14 +3,21 @@
 // Persistent waves; each lane owns one ray for its whole life (ray state in registers).  A wave takes rays
 // from the global queue 512 at a time (one atomic per 512 rays) and hands them to idle lanes with
 // ballot + mbcnt, so lanes whose path ended are refilled at once.  Per segment each lane walks the BVH with its
-// own LDS stack (depth-major layout: no bank conflicts), nearest child first, pruning boxes whose entry distance
-// exceeds the best hit so far.  The slab test runs in f64 on the f32 boxes (rounded outward + inflated at build
-// time), the leaves run the exact f64 sphere test of sphere.rs:19-30, planes and triangles are tested exactly and
-// exhaustively (they cannot be culled: plane.rs is unbounded, triangle.rs has phantom hits), and the winner is the
-// lexicographic minimum of (t, scene index) -- the reference's first-minimal rule.  Same bits as trace_exact_kernel.
+// own LDS stack (depth-major layout: no bank conflicts).  Nodes are 4-wide (128 B: the boxes of up to four
+// children inline), so a step is ONE dependent fetch; children are visited nearest first and boxes whose entry
+// distance exceeds the best hit so far are pruned.
 //
-// Bound: latency/L2-bandwidth of the node fetches (32 B per node, ~2 nodes per visit); algorithmic bytes per
-// segment = nodes_visited * 32 + leaf_tests * 32 (BVH config), both counted by the kernel.
+// Exactness.  The tree only decides WHICH spheres get the exact f64 test of sphere.rs:19-30; it never decides a
+// hit.  (1) Boxes: f32, rounded outward, inflated (rtx_bvh.h); the f32 slab test below widens its interval by the
+// relative rounding error, so it cannot reject a box that contains a reportable intersection.  (2) Leaves: each
+// sphere first passes the conservative f32 discriminant filter of the sweep kernel (rtx_device.h), survivors get
+// the exact test.  (3) Pruning keeps ties (entry <= best), and the winner is the lexicographic minimum of
+// (t, scene index) -- the reference's first-minimal rule.  Planes and triangles are tested exactly and
+// exhaustively (plane.rs is unbounded, triangle.rs has phantom hits: neither can be culled).  Rays whose origin is
+// outside the range the f32 test was validated for sweep all spheres exactly.  Same bits as trace_exact_kernel.
+//
+// Bound: latency / L2 bandwidth of the node fetches; algorithmic bytes per segment = box_tests * 32 +
+// leaf_filter_tests * 16 + exact_tests * 32 (BVH config), all counted by the kernel.
 #include "rtx_launch.h"
 
 namespace rtx {
@@ -26,20 +33,50 @@ __device__ __forceinline__ uint32_t bvh_mbcnt(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// f64 slab test of the ray against a node box; returns the entry distance or +inf on a miss.
-// fmin/fmax return the non-NaN operand (0 * inf when an origin lies on a slab of an axis-parallel ray), which
-// only widens the interval: conservative.
-__device__ __forceinline__ double box_entry(const float4 lo, const float4 hi, const V3 o, const V3 inv, double best)
+struct Ray32 { float ox, oy, oz, ix, iy, iz; };
+
+// f32 slab test; returns a lower bound of the entry distance, or +inf on a certain miss.
+//   t = fl(fl(b - fl(o)) * fl(1/d)): the origin rounding is covered by the boxes' absolute padding (rtx_bvh.h);
+//   the remaining roundings are a relative error < 2^-22 on every t, so the interval is widened by 2^-21 |t|.
+// fminf/fmaxf return the non-NaN operand (0 * inf: origin on a slab of an axis-parallel ray), which only widens
+// the interval; an infinite tn/tf of a ray that runs outside a slab turns the widened bound into NaN and the
+// comparison into "miss", which is the right answer.
+__device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, const Ray32 &r, float best_up)
 {
-    const double x0 = ((double)lo.x - o.x) * inv.x, x1 = ((double)hi.x - o.x) * inv.x;
-    const double y0 = ((double)lo.y - o.y) * inv.y, y1 = ((double)hi.y - o.y) * inv.y;
-    const double z0 = ((double)lo.z - o.z) * inv.z, z1 = ((double)hi.z - o.z) * inv.z;
-    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
-    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
-    // the boxes carry a 2^-20 relative inflation, the f64 slab arithmetic errs by ~1e-15 relative: no further slack
-    // is needed, but ties (tn == best) must be kept for the first-wins rule
-    const bool hit = (tn <= tf) && (tf >= 0.0) && (tn <= best);
-    return hit ? tn : (double)INFINITY;
+    const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
+    const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
+    const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const float eps = 4.76837158e-7f;                                   // 2^-21
+    const float tn_lo = __builtin_fmaf(-eps, __builtin_fabsf(tn), tn);
+    const float tf_hi = __builtin_fmaf(eps, __builtin_fabsf(tf), tf);
+    const bool hit = (tn_lo <= tf_hi) && (tf_hi >= 0.0f) && (tn_lo <= best_up);
+    return hit ? tn_lo : __builtin_inff();      // the widened (conservative) entry distance
+}
+
+// best (f64) rounded UP to f32 for the pruning comparison
+__device__ __forceinline__ float round_up32(double best)
+{
+    float b = (float)best;
+    if ((double)b < best) b = __uint_as_float(__float_as_uint(b) + (b >= 0.0f ? 1u : 0xFFFFFFFFu));
+    return b;
+}
+
+constexpr int kBvhQueue = 8;               // candidate spheres a lane may hold between two exact passes
+
+// Exact f64 tests (sphere.rs:19-30) of the queued candidates; updates the winner and the pruning bound.
+__device__ __forceinline__ void flush_candidates(const SceneView &sv, const RayX &rx, const uint32_t *lds_q, uint32_t tid,
+                                                 uint32_t &qcnt, Hit &h, float &best_up, unsigned long long &exact)
+{
+    for (uint32_t k = 0; k < qcnt; ++k) {
+        const uint32_t idx = lds_q[(size_t)k * kBvhThreads + tid];
+        double t;
+        if (sphere_distance(sv.spheres[idx], rx, &t)) hit_consider(h, t, sv.sphere_id[idx], 0, idx);
+    }
+    exact += qcnt;
+    qcnt = 0;
+    if (h.id != kNone) best_up = round_up32(h.t);
 }
 
 }  // namespace
@@ -51,7 +88,8 @@ __global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneVi
 {
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
-    __shared__ uint32_t lds_stack[kBvhMaxDepth + 2][kBvhThreads];
+    __shared__ uint32_t lds_stack[kBvh4StackEntries][kBvhThreads];
+    __shared__ uint32_t lds_q[kBvhQueue][kBvhThreads];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
@@ -62,7 +100,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneVi
     bool alive = false;
     RayState r;
     uint32_t pl = 0, smp = 0;
-    unsigned long long segs = 0, node_visits = 0, leaf_tests = 0;
+    unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
 
     for (;;) {
         // ---- hand rays to idle lanes: ballot + prefix sum over the wave's local range, one atomic per 512 rays
@@ -101,65 +139,91 @@ __global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneVi
         if (alive) {
             // ---- one segment: closest_object (scene.rs:243-251)
             const RayX rx = make_rayx(r.pos, r.dir);
-            const V3 inv = mk(1.0 / rx.dirn.x, 1.0 / rx.dirn.y, 1.0 / rx.dirn.z);
             Hit h;
             hit_init(h);
-            double best = (double)INFINITY;
             ++segs;
-            if (sv.n_bvh_nodes != 0) {
-                uint32_t sp = 0;
-                uint32_t node = 0;
-                {
-                    const float4 lo = nodes[0], hi = nodes[1];
-                    if (!(box_entry(lo, hi, r.pos, inv, best) < (double)INFINITY)) node = kNone;
-                    ++node_visits;
-                }
+            const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
+                                     __builtin_fabsf((float)r.pos.z));
+            if (sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit) {          // NaN origin -> exhaustive branch
+                Ray32 q;
+                q.ox = (float)r.pos.x; q.oy = (float)r.pos.y; q.oz = (float)r.pos.z;
+                q.ix = (float)(1.0 / rx.dirn.x); q.iy = (float)(1.0 / rx.dirn.y); q.iz = (float)(1.0 / rx.dirn.z);
+                FilterParams fpar;
+                filter_from_ray(sv, r.pos, r.dir, fpar);
+                float best_up = __builtin_inff();
+                uint32_t sp = 0, qcnt = 0, step = 0;
+                bool overflow = false;
+                uint32_t node = 0;                       // wide node 0 is the root
                 while (node != kNone) {
-                    const float4 lo = nodes[2 * (size_t)node], hi = nodes[2 * (size_t)node + 1];
-                    const uint32_t link = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
-                    if (count != 0u) {
-                        for (uint32_t k = 0; k < count; ++k) {
-                            const uint32_t idx = sv.bvh_prims[link + k];
-                            double t;
-                            if (sphere_distance(sv.spheres[idx], rx, &t)) {
-                                hit_consider(h, t, sv.sphere_id[idx], 0, idx);
-                                if (h.id != kNone) best = h.t;
+                    // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
+                    const float4 *np = nodes + 8 * (size_t)node;
+                    float4 ca[4], cb[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+                    float tc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+                    box_tests += 4;
+                    // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
+                    // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
+                    // sphere) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t count = __float_as_uint(cb[c].w);
+                        if (tc[c] < __builtin_inff() && count - 1u < (uint32_t)kBvhLeafSize) {
+                            const uint32_t first = __float_as_uint(ca[c].w);
+                            if (qcnt + count > (uint32_t)kBvhQueue)
+                                flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                            for (uint32_t k = 0; k < count; ++k) {
+                                const float4 rec = sv.bvh_leaf_f32[first + k];
+                                if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
+                                    lds_q[qcnt][tid] = sv.bvh_prims[first + k];
+                                    qcnt += 1;
+                                }
                             }
-                        }
-                        leaf_tests += count;
-                        node = kNone;
-                    } else {
-                        const uint32_t left = node + 1u, right = link;
-                        const float4 llo = nodes[2 * (size_t)left], lhi = nodes[2 * (size_t)left + 1];
-                        const float4 rlo = nodes[2 * (size_t)right], rhi = nodes[2 * (size_t)right + 1];
-                        const double tl = box_entry(llo, lhi, r.pos, inv, best);
-                        const double tr = box_entry(rlo, rhi, r.pos, inv, best);
-                        node_visits += 2;
-                        const bool hl = tl < (double)INFINITY, hr = tr < (double)INFINITY;
-                        if (hl && hr) {
-                            const bool left_first = tl <= tr;
-                            lds_stack[sp][tid] = left_first ? right : left;
-                            sp += 1;
-                            node = left_first ? left : right;
-                        } else {
-                            node = hl ? left : (hr ? right : kNone);
+                            leaf_filters += count;
                         }
                     }
-                    // pop until a node whose box can still hold a closer (or tied) hit
-                    while (node == kNone && sp != 0u) {
+                    step += 1;
+                    if ((step & 3u) == 0u) flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                    // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
+                    float key[4];
+                    uint32_t lnk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool go = __float_as_uint(cb[c].w) == 0u && tc[c] < __builtin_inff() && tc[c] <= best_up;
+                        key[c] = go ? tc[c] : __builtin_inff();
+                        lnk[c] = __float_as_uint(ca[c].w);
+                    }
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
+                    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+                    // push the farther ones (farthest first), descend into the nearest
+                    // (stack + queue = 32 words of LDS per lane, which is what 16 waves per CU leave; a ray that would
+                    // need more than the 24 stack entries finishes with the exhaustive sweep below)
+                    if (key[3] < __builtin_inff()) { if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = lnk[3]; sp += 1; } else overflow = true; }
+                    if (key[2] < __builtin_inff()) { if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = lnk[2]; sp += 1; } else overflow = true; }
+                    if (key[1] < __builtin_inff()) { if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = lnk[1]; sp += 1; } else overflow = true; }
+                    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+                    if (node == kNone && sp != 0u) {
                         sp -= 1;
-                        const uint32_t cand = lds_stack[sp][tid];
-                        const float4 clo = nodes[2 * (size_t)cand], chi = nodes[2 * (size_t)cand + 1];
-                        ++node_visits;
-                        if (box_entry(clo, chi, r.pos, inv, best) < (double)INFINITY) node = cand;
+                        node = lds_stack[sp][tid];      // its boxes are re-tested against the current bound when it is opened
                     }
+                }
+                flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                if (overflow) {                       // some subtree was dropped: every sphere gets the exact test
+                    for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+                        double t;
+                        if (sphere_distance(sv.spheres[k], rx, &t)) hit_consider(h, t, sv.sphere_id[k], 0, k);
+                    }
+                    exact += sv.n_spheres;
                 }
             } else {
                 for (uint32_t k = 0; k < sv.n_spheres; ++k) {
                     double t;
                     if (sphere_distance(sv.spheres[k], rx, &t)) hit_consider(h, t, sv.sphere_id[k], 0, k);
                 }
-                leaf_tests += sv.n_spheres;
+                exact += sv.n_spheres;
             }
             for (uint32_t k = 0; k < sv.n_planes; ++k) {
                 double t;
@@ -169,6 +233,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneVi
                 double t;
                 if (triangle_distance(sv.tris[k], rx, &t)) hit_consider(h, t, sv.tris[k].id, 2, k);
             }
+            exact += sv.n_planes + sv.n_tris;
 
             // ---- render_ray's match arm + ray_hit (scene.rs:232-239, 260-278)
             bool done = true;
@@ -183,19 +248,21 @@ __global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneVi
             }
         }
     }
-    // counters: segments, exact f64 shape tests, BVH node visits (reported through filter_tests)
-    unsigned long long exact = leaf_tests + segs * (sv.n_planes + sv.n_tris);
+    // counters: segments, exact f64 shape tests, box tests + leaf filter tests (reported through filter_tests)
+    unsigned long long filt = box_tests + leaf_filters;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         segs += __shfl_xor(segs, off, 64);
         exact += __shfl_xor(exact, off, 64);
-        node_visits += __shfl_xor(node_visits, off, 64);
+        filt += __shfl_xor(filt, off, 64);
+        box_tests += __shfl_xor(box_tests, off, 64);
     }
     if (lane == 0) {
         const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
         if (segs) atomicAdd(&ctr[shard].segments, segs);
         if (exact) atomicAdd(&ctr[shard].exact_tests, exact);
-        if (node_visits) atomicAdd(&ctr[shard].filter_tests, node_visits);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);   // shards 0,1 carry debug flags
     }
 }
 

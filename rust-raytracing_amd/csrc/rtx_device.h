@@ -30,10 +30,13 @@ struct SceneView {
     double          sphere_center[3];          // centre of the spheres' bounding box
     double          sphere_cmax;               // max over spheres of |c - centre| + r
     // flat BVH over the spheres (rtx_bvh.h); null when the scene has none
-    const BvhNode  *bvh_nodes;
+    const Bvh4Node *bvh_nodes;                 // 4-wide nodes, 128 B each; node 0 is the root
     const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
+    const float4   *bvh_leaf_f32;              // per leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
     uint32_t        n_bvh_nodes;
     uint32_t        bvh_depth;
+    float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
+    float           pad_;
 };
 
 // Which pixels/samples one launch covers.
@@ -169,6 +172,50 @@ __device__ __forceinline__ void advance_and_shade(const SceneView &sv, const Hit
 __device__ __forceinline__ bool light_is_zero(const RayState &r)               // scene.rs:228
 {
     return r.light.x == 0.0 && r.light.y == 0.0 && r.light.z == 0.0;
+}
+
+// ---- conservative f32 sphere filter (trace_mixed_kernel's sweep, trace_bvh_kernel's leaves); see rtx_kernels.hip
+struct FilterParams { float dx, dy, dz, npd, p2x, p2y, p2z, nppE; };
+
+__device__ __forceinline__ void filter_idle(FilterParams &f)      // D = -3e30 - w < 0: nothing passes
+{
+    f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
+    f.nppE = -3.0e30f;
+}
+
+__device__ __forceinline__ void filter_pass_all(FilterParams &f)  // D = 1e30 - w >= 0: every record is a candidate
+{
+    f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
+    f.nppE = 1.0e30f;
+}
+
+// Magnitudes outside 1e-12 < M < 1e14 could overflow/underflow the f32 products: such a ray gets the
+// pass-all filter (its queue overflows and the slot takes the exact f64 sweep).  Inside the range every
+// filter operation stays finite, so the sweep's sign-bit test is exact: D >= 0 <=> sign bit clear.
+__device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
+{
+    // centre the origin (better conditioned f32 products); all in f64, then one rounding each
+    double px = pos.x - sv.sphere_center[0];
+    double py = pos.y - sv.sphere_center[1];
+    double pz = pos.z - sv.sphere_center[2];
+    double pp = px * px + py * py + pz * pz;
+    double pd = px * dir.x + py * dir.y + pz * dir.z;
+    // error bound: |D_f32 - D| <= 24 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md 3.1); E = 64 * 2^-24 * M^2
+    double M = sv.sphere_cmax + sqrt(pp);
+    if (!(M < 1.0e14) || !(M > 1.0e-12)) { filter_pass_all(f); return; }
+    double E = M * M * (64.0 / 16777216.0);
+    f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
+    f.npd = (float)(-pd);
+    f.p2x = (float)(2.0 * px); f.p2y = (float)(2.0 * py); f.p2z = (float)(2.0 * pz);
+    f.nppE = (float)(E - pp);
+}
+
+// D for one sphere record {c - centre (xyz), |c - centre|^2 - r^2}
+__device__ __forceinline__ float filter_disc1(const float4 s, const FilterParams &f)
+{
+    float b = __builtin_fmaf(s.x, f.dx, __builtin_fmaf(s.y, f.dy, __builtin_fmaf(s.z, f.dz, f.npd)));
+    float q = __builtin_fmaf(s.x, f.p2x, __builtin_fmaf(s.y, f.p2y, __builtin_fmaf(s.z, f.p2z, f.nppE)));
+    return __builtin_fmaf(b, b, q - s.w);
 }
 
 }  // namespace rtx

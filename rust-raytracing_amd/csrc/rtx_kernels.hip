@@ -129,40 +129,6 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 //     float4 A = {x0, x1, y0, y1}   float4 B = {z0, z1, w0, w1},   w = |c|^2 - r^2
 // and the slot holds {d.xyz, -p.d, 2p.xyz, -p.p + E}.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct FilterParams { float dx, dy, dz, npd, p2x, p2y, p2z, nppE; };
-
-__device__ __forceinline__ void filter_idle(FilterParams &f)      // D = -3e30 - w < 0: nothing passes
-{
-    f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
-    f.nppE = -3.0e30f;
-}
-
-__device__ __forceinline__ void filter_pass_all(FilterParams &f)  // D = 1e30 - w >= 0: every record is a candidate
-{
-    f.dx = f.dy = f.dz = f.npd = f.p2x = f.p2y = f.p2z = 0.0f;
-    f.nppE = 1.0e30f;
-}
-
-// Magnitudes outside 1e-12 < M < 1e14 could overflow/underflow the f32 products: such a ray gets the
-// pass-all filter (its queue overflows and the slot takes the exact f64 sweep).  Inside the range every
-// filter operation stays finite, so the sweep's sign-bit test is exact: D >= 0 <=> sign bit clear.
-__device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 dir, FilterParams &f)
-{
-    // centre the origin (better conditioned f32 products); all in f64, then one rounding each
-    double px = pos.x - sv.sphere_center[0];
-    double py = pos.y - sv.sphere_center[1];
-    double pz = pos.z - sv.sphere_center[2];
-    double pp = px * px + py * py + pz * pz;
-    double pd = px * dir.x + py * dir.y + pz * dir.z;
-    // error bound: |D_f32 - D| <= 24 * 2^-24 * M^2,  M = max(|c| + r) + |p|  (DESIGN.md 3.1); E = 64 * 2^-24 * M^2
-    double M = sv.sphere_cmax + sqrt(pp);
-    if (!(M < 1.0e14) || !(M > 1.0e-12)) { filter_pass_all(f); return; }
-    double E = M * M * (64.0 / 16777216.0);
-    f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
-    f.npd = (float)(-pd);
-    f.p2x = (float)(2.0 * px); f.p2y = (float)(2.0 * py); f.p2z = (float)(2.0 * pz);
-    f.nppE = (float)(E - pp);
-}
 
 // D for the two spheres of one LDS pair record
 __device__ __forceinline__ f32x2 filter_disc2(const float4 A, const float4 B, const FilterParams &f)

@@ -11,5 +11,5 @@ for kern in (rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_MIXED):
     for it in range(2):
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
     print("kernel", kern, "trace %.2f ms" % st.trace_ms, "Mrays/s %.1f" % (w*h*spp/st.trace_ms/1e3), "segments", st.segments,
-          "exact/seg %.2f" % (st.exact_tests/st.segments), "filter-or-nodes/seg %.1f" % (st.filter_tests/st.segments))
+          "exact/seg %.2f" % (st.exact_tests/st.segments), "filter/seg %.1f" % (st.filter_tests/st.segments), "box/seg %.1f" % (st.box_tests/st.segments))
     hnd.close()
