@@ -229,7 +229,11 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
                 }
                 break;
             case RTX_PLANE: planes.push_back(make_plane(o.geom, (uint32_t)k)); break;
-            case RTX_TRIANGLE: tris.push_back(make_triangle(o.geom, (uint32_t)k)); break;
+            case RTX_TRIANGLE:
+                tris.push_back(make_triangle(o.geom, (uint32_t)k));
+                for (int c = 0; c < 9; ++c)
+                    if (std::isfinite(o.geom[c])) { lo[c % 3] = std::fmin(lo[c % 3], o.geom[c]); hi[c % 3] = std::fmax(hi[c % 3], o.geom[c]); }
+                break;
             default:
                 free_handle(h);
                 return fail(RTX_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": kind " + std::to_string(o.kind) +
@@ -262,6 +266,42 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
         sph32[k] = make_float4(fx[k], fx[k + 1], fy[k], fy[k + 1]);
         sph32[k + 1] = make_float4(fz[k], fz[k + 1], fw[k], fw[k + 1]);
     }
+    // triangle filter records (rtx_device.h "triangle filter"): only triangles that can be hit at all
+    std::vector<float4> tri32;
+    std::vector<uint32_t> tri_fidx;
+    double tri_extent = 0.0;
+    for (size_t k = 0; k < tris.size(); ++k) {
+        const TriX &t = tris[k];
+        const RtxObject &o = scene->objects[t.id];
+        if (t.degenerate) continue;                                   // Triangle::contains is always false (triangle.rs:64,83)
+        const double kabs = dot(t.n, t.v0);
+        if (!std::isfinite(kabs) || !std::isfinite(t.n.x) || !std::isfinite(t.n.y) || !std::isfinite(t.n.z))
+            continue;                                                 // NaN normal: every comparison of the exact test fails
+        if (kabs < -(1.0 + 1e-9)) continue;                           // n.(v0 - dir) < 0 for every unit dir (triangle.rs:115)
+        double v[3][3];
+        bool finite = true;
+        for (int c = 0; c < 9; ++c) { v[c / 3][c % 3] = o.geom[c] - centre[c % 3]; finite = finite && std::isfinite(o.geom[c]); }
+        const double rx = v[1][0] - v[0][0], ry = v[1][1] - v[0][1], sx = v[2][0] - v[0][0], sy = v[2][1] - v[0][1];
+        const double det = rx * sy - ry * sx;
+        const bool rows_xy = (t.i == 0 && t.j == 1);
+        const bool plain = finite && rows_xy && std::fabs(det) > 1e-6 * std::hypot(rx, ry) * std::hypot(sx, sy);
+        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = make_float4(0.f, 0.f, 0.f, 0.f);      // "always a candidate"
+        if (plain) {
+            const double xlo = std::fmin(v[0][0], std::fmin(v[1][0], v[2][0])), xhi = std::fmax(v[0][0], std::fmax(v[1][0], v[2][0]));
+            const double ylo = std::fmin(v[0][1], std::fmin(v[1][1], v[2][1])), yhi = std::fmax(v[0][1], std::fmax(v[1][1], v[2][1]));
+            const double kc = t.n.x * v[0][0] + t.n.y * v[0][1] + t.n.z * v[0][2];
+            const double grow = 1.0 + 1.0 / 1048576.0;
+            A = make_float4((float)t.n.x, (float)t.n.y, (float)t.n.z, (float)kc);
+            B = make_float4((float)(0.5 * (xlo + xhi)), (float)(0.5 * (ylo + yhi)),
+                            round_up_f32(0.5 * (xhi - xlo) * grow + 1e-30), round_up_f32(0.5 * (yhi - ylo) * grow + 1e-30));
+            for (int c = 0; c < 9; ++c) tri_extent = std::fmax(tri_extent, std::fabs(v[c / 3][c % 3]));
+        }
+        tri32.push_back(A);
+        tri32.push_back(B);
+        tri_fidx.push_back((uint32_t)k);
+    }
+    h->sv.n_tri_filter = (uint32_t)tri_fidx.size();
+    h->sv.tri_extent = tri_extent;
     h->sv.n_objects = (uint32_t)n;
     h->sv.n_spheres = (uint32_t)spheres.size();
     h->sv.n_planes = (uint32_t)planes.size();
@@ -304,6 +344,8 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     if (!rc) rc = upload_vec(h, tris, &h->sv.tris);
     if (!rc) rc = upload_vec(h, mats, &h->sv.materials);
     if (!rc) rc = upload_vec(h, sph32, &h->sv.sphere_f32);
+    if (!rc) rc = upload_vec(h, tri32, &h->sv.tri_f32);
+    if (!rc) rc = upload_vec(h, tri_fidx, &h->sv.tri_fidx);
     if (rc) { free_handle(h); return rc; }
 
     hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
@@ -346,8 +388,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     const uint32_t npix = n_rows * width;
     const uint64_t spp = h->cfg.rays_per_pixel;
-    // AUTO: the BVH kernel when a sphere BVH was built at upload (> 4 finite spheres), else the LDS sweep
-    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? (h->sv.n_bvh_nodes != 0 ? RTX_KERNEL_BVH : RTX_KERNEL_MIXED)
+    // AUTO: the BVH kernel when a sphere BVH was built at upload (> 4 finite spheres) and the scene has few triangles
+    // (that kernel tests triangles exhaustively in f64), else the LDS sweep with its sphere and triangle filters
+    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? (h->sv.n_bvh_nodes != 0 && h->sv.n_tri_filter <= 32 ? RTX_KERNEL_BVH : RTX_KERNEL_MIXED)
                                                               : h->cfg.kernel;
 
     // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row

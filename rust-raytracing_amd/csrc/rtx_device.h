@@ -25,9 +25,17 @@ struct SceneView {
     const TriX     *tris;
     const MaterialX *materials;                // by scene index
     // f32 filter records for the MIXED kernel
+    // f32 filter records of the triangles that can be hit at all (MIXED kernel's triangle sweep): 2 x float4 each,
+    // {n.xyz, n.(v0 - centre)} {cx, cy, hx, hy} = unit normal, plane offset, centre/half-size of the triangle's box in
+    // the (x, y) projection Triangle::contains solves in (triangle.rs:55-100); tri_fidx maps a record to tris[]
+    const float4   *tri_f32;
+    const uint32_t *tri_fidx;
+    uint32_t        n_tri_filter;
+    uint32_t        pad0_;
+    double          tri_extent;                // max over filtered triangles of |vertex - centre|_inf
     const float4   *sphere_f32;                // pair-interleaved {x0,x1,y0,y1},{z0,z1,w0,w1}; c - centre, w = |c|^2 - r*r;
                                                // padded to a multiple of 4 spheres
-    double          sphere_center[3];          // centre of the spheres' bounding box
+    double          sphere_center[3];          // centre of the bounding box of sphere centres and triangle vertices
     double          sphere_cmax;               // max over spheres of |c - centre| + r
     // flat BVH over the spheres (rtx_bvh.h); null when the scene has none
     const Bvh4Node *bvh_nodes;                 // 4-wide nodes, 128 B each; node 0 is the root
@@ -208,6 +216,54 @@ __device__ __forceinline__ void filter_from_ray(const SceneView &sv, V3 pos, V3 
     f.npd = (float)(-pd);
     f.p2x = (float)(2.0 * px); f.p2y = (float)(2.0 * py); f.p2z = (float)(2.0 * pz);
     f.nppE = (float)(E - pp);
+}
+
+// ---- conservative f32 triangle filter -----------------------------------------------------------------------
+// Triangle::distance (triangle.rs:108-127) reports a hit only if the point q = p + dir * |n.(v0-p) / n.d| has its
+// (x, y) projection inside the projected triangle (rows x, y of the elimination; upload keeps other pivot rows and
+// ill-conditioned projections as "always candidate").  Inside the triangle implies inside its projected bounding
+// box |q_x - c_x| <= h_x, |q_y - c_y| <= h_y.  Multiplied by |n.d| the test needs no division:
+//     e_x = (p_x - c_x) |n.d| + d_x |n.(v0 - p)|,      candidate  <=>  |e_x| <= h_x |n.d| + A   (same for y)
+// With u = 2^-24 and S >= every coordinate magnitude (relative to the scene centre), the f32 evaluation of e_x is
+// off by <= 31 u S and of the right-hand side by <= 13 u S; A = 64 u S.  The cull test (triangle.rs:115) is not
+// evaluated here: triangles it always rejects were dropped at upload, the others are left to the exact test.
+struct TriFilterParams { float dx, dy, dz, npx, npy, npz, A, pad; };
+
+__device__ __forceinline__ void tri_filter_idle(TriFilterParams &f)
+{
+    f.dx = f.dy = f.dz = f.npx = f.npy = f.npz = f.pad = 0.0f;
+    f.A = -3.0e30f;
+}
+
+__device__ __forceinline__ void tri_filter_pass_all(TriFilterParams &f)
+{
+    f.dx = f.dy = f.dz = f.npx = f.npy = f.npz = f.pad = 0.0f;
+    f.A = 1.0e30f;
+}
+
+__device__ __forceinline__ void tri_filter_from_ray(const SceneView &sv, V3 pos, V3 dir, TriFilterParams &f)
+{
+    const double px = pos.x - sv.sphere_center[0], py = pos.y - sv.sphere_center[1], pz = pos.z - sv.sphere_center[2];
+    const double S = sv.tri_extent + fabs(px) + fabs(py) + fabs(pz) + 1.0;
+    if (!(S < 1.0e14)) { tri_filter_pass_all(f); return; }
+    f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
+    f.npx = (float)(-px); f.npy = (float)(-py); f.npz = (float)(-pz);
+    f.A = (float)(S * (64.0 / 16777216.0));
+    f.pad = 0.0f;
+}
+
+// value whose sign bit is clear <=> the triangle record is a candidate for this ray
+__device__ __forceinline__ uint32_t tri_filter_sign(const float4 A, const float4 B, const TriFilterParams &f)
+{
+    const float dn = __builtin_fmaf(A.x, f.dx, __builtin_fmaf(A.y, f.dy, A.z * f.dz));
+    const float nv = __builtin_fmaf(A.x, f.npx, __builtin_fmaf(A.y, f.npy, __builtin_fmaf(A.z, f.npz, A.w)));
+    const float adn = __builtin_fabsf(dn), anv = __builtin_fabsf(nv);
+    const float ax = -f.npx - B.x, ay = -f.npy - B.y;
+    const float ex = __builtin_fmaf(ax, adn, f.dx * anv);
+    const float ey = __builtin_fmaf(ay, adn, f.dy * anv);
+    const float sx = __builtin_fmaf(B.z, adn, f.A) - __builtin_fabsf(ex);
+    const float sy = __builtin_fmaf(B.w, adn, f.A) - __builtin_fabsf(ey);
+    return __float_as_uint(sx) | __float_as_uint(sy);
 }
 
 // D for one sphere record {c - centre (xyz), |c - centre|^2 - r^2}

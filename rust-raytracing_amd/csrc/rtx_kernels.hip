@@ -145,11 +145,11 @@ __device__ __forceinline__ f32x2 filter_disc2(const float4 A, const float4 B, co
 
 // Per-slot data that lives between rounds, structure-of-arrays in HBM (slot = lane_gid + s * n_lanes):
 //   state  [12][n_slots] f64   ray.position, ray.direction, resulting_color, light_color  (ray.rs:4-21)
-//   fstate [ 8][n_slots] f32   the slot's filter parameters
+//   fstate [16][n_slots] f32   the slot's sphere-filter (0-7) and triangle-filter (8-15) parameters
 //   istate [ 3][n_slots] u32   local pixel, batch-local sample, bounce count
 // Only a one-bit-per-slot `live` mask stays in registers across rounds, so the heavy f64 code (primary ray
 // generation, exact tests, shading) exists once and loops over the slots instead of being unrolled S times.
-constexpr size_t kSlotBytes = 12 * sizeof(double) + 8 * sizeof(float) + 3 * sizeof(uint32_t);
+constexpr size_t kSlotBytes = 12 * sizeof(double) + 16 * sizeof(float) + 3 * sizeof(uint32_t);
 
 template <int S, int THREADS, int CHUNK, int Q, int WAVES_PER_EU>
 __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(const SceneView *__restrict__ svp,
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
     const uint64_t lane_gid = (uint64_t)blockIdx.x * THREADS + tid;
     double *state = reinterpret_cast<double *>(slot_mem);
     float *fstate = reinterpret_cast<float *>(state + 12 * n_slots);
-    uint32_t *istate = reinterpret_cast<uint32_t *>(fstate + 8 * n_slots);
+    uint32_t *istate = reinterpret_cast<uint32_t *>(fstate + 16 * n_slots);
     const uint32_t ns = sv.n_spheres;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
@@ -236,6 +236,12 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                             float *fs = fstate + slot;
                             fs[0 * n_slots] = f.dx; fs[1 * n_slots] = f.dy; fs[2 * n_slots] = f.dz; fs[3 * n_slots] = f.npd;
                             fs[4 * n_slots] = f.p2x; fs[5 * n_slots] = f.p2y; fs[6 * n_slots] = f.p2z; fs[7 * n_slots] = f.nppE;
+                    {
+                        TriFilterParams tf;
+                        if (sv.n_tri_filter != 0) tri_filter_from_ray(sv, r.pos, r.dir, tf); else tri_filter_idle(tf);
+                        fs[8 * n_slots] = tf.dx; fs[9 * n_slots] = tf.dy; fs[10 * n_slots] = tf.dz; fs[11 * n_slots] = tf.npx;
+                        fs[12 * n_slots] = tf.npy; fs[13 * n_slots] = tf.npz; fs[14 * n_slots] = tf.A;
+                    }
                             uint32_t *is = istate + slot;
                             is[0 * n_slots] = p; is[1 * n_slots] = sl; is[2 * n_slots] = 0u;
                             live |= 1u << s;
@@ -298,6 +304,54 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                 }
             }
         }
+        // ---- the same for the triangles that can be hit at all: 32-byte records {n, n.(v0-c)} {cx, cy, hx, hy}
+        if (sv.n_tri_filter != 0) {
+            const uint32_t nt = sv.n_tri_filter;
+            constexpr uint32_t TCHUNK = CHUNK / 2;                  // records per LDS load (2 float4 each)
+            TriFilterParams tp[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                tri_filter_idle(tp[s]);
+                if ((live >> s) & 1u) {
+                    const float *fs = fstate + (lane_gid + (uint64_t)s * n_lanes);
+                    tp[s].dx = fs[8 * n_slots]; tp[s].dy = fs[9 * n_slots]; tp[s].dz = fs[10 * n_slots]; tp[s].npx = fs[11 * n_slots];
+                    tp[s].npy = fs[12 * n_slots]; tp[s].npz = fs[13 * n_slots]; tp[s].A = fs[14 * n_slots];
+                }
+            }
+            for (uint32_t c0 = 0; c0 < nt; c0 += TCHUNK) {
+                const uint32_t n = (nt - c0 < TCHUNK) ? nt - c0 : TCHUNK;
+                if (c0 != 0 || ns != 0) __syncthreads();           // everyone is done with the previous LDS contents
+                for (uint32_t j = tid; j < 2 * n; j += THREADS) lds_sph[j] = sv.tri_f32[2 * (size_t)c0 + j];
+                __syncthreads();
+#pragma unroll 1
+                for (uint32_t j = 0; j < n; j += 2) {
+                    const bool two = j + 1 < n;
+                    const float4 A0 = lds_sph[2 * j], B0 = lds_sph[2 * j + 1];
+                    const float4 A1 = two ? lds_sph[2 * j + 2] : A0, B1 = two ? lds_sph[2 * j + 3] : B0;
+                    uint32_t sg[S][2];
+                    uint32_t sign_and = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        sg[s][0] = tri_filter_sign(A0, B0, tp[s]);
+                        sg[s][1] = two ? tri_filter_sign(A1, B1, tp[s]) : 0x80000000u;
+                        sign_and &= sg[s][0] & sg[s][1];
+                    }
+                    if ((int)sign_and >= 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                if ((int)sg[s][k] >= 0) {
+                                    if (cnt[s] < (uint32_t)Q)
+                                        lds_q[((size_t)cnt[s] * S + s) * THREADS + tid] = 0x80000000u | sv.tri_fidx[c0 + j + k];
+                                    cnt[s] += 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) lds_cnt[s * THREADS + tid] = cnt[s];
         rounds_swept += 1;
@@ -319,22 +373,27 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
             hit_init(h);
             ++segs;
             if (ncand > (uint32_t)Q) {
-                // more candidates than the queue holds (many spheres along one line, or a pass-all filter): exact sweep
+                // more candidates than the queue holds (many shapes along one line, or a pass-all filter): exact sweep
                 closest_spheres_exact(sv, rx, h);
-                exact += ns;
+                closest_tris_exact(sv, rx, h);
+                exact += ns + sv.n_tris;
             } else {
                 for (uint32_t k = 0; k < ncand; ++k) {
                     const uint32_t idx = lds_q[((size_t)k * S + s) * THREADS + tid];
-                    if (idx < ns) {
-                        double t;
+                    double t;
+                    if (idx & 0x80000000u) {                                  // a triangle candidate
+                        const uint32_t ti = idx & 0x7FFFFFFFu;
+                        if (ti < sv.n_tris && triangle_distance(sv.tris[ti], rx, &t)) hit_consider(h, t, sv.tris[ti].id, 2, ti);
+                    } else if (idx < ns) {
                         if (sphere_distance(sv.spheres[idx], rx, &t)) hit_consider(h, t, sv.sphere_id[idx], 0, idx);
                     }
                 }
                 exact += ncand;
-                if (verify) {            // debug: the filter must never lose the exact winner
+                if (verify) {            // debug: the filters must never lose the exact winner
                     Hit hv;
                     hit_init(hv);
                     closest_spheres_exact(sv, rx, hv);
+                    closest_tris_exact(sv, rx, hv);
                     if (hv.id != h.id || (hv.id != kInvalid && hv.t != h.t)) {
                         ++mism;
                         if (verify > 1 && mism < 3)
@@ -345,8 +404,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                 }
             }
             closest_planes_exact(sv, rx, h);
-            closest_tris_exact(sv, rx, h);
-            exact += sv.n_planes + sv.n_tris;
+            exact += sv.n_planes;
 
             r.result = mk(st[6 * n_slots], st[7 * n_slots], st[8 * n_slots]);
             bool done = true;
@@ -371,6 +429,12 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                     float *fs = fstate + slot;
                     fs[0 * n_slots] = f.dx; fs[1 * n_slots] = f.dy; fs[2 * n_slots] = f.dz; fs[3 * n_slots] = f.npd;
                     fs[4 * n_slots] = f.p2x; fs[5 * n_slots] = f.p2y; fs[6 * n_slots] = f.p2z; fs[7 * n_slots] = f.nppE;
+                    {
+                        TriFilterParams tf;
+                        if (sv.n_tri_filter != 0) tri_filter_from_ray(sv, r.pos, r.dir, tf); else tri_filter_idle(tf);
+                        fs[8 * n_slots] = tf.dx; fs[9 * n_slots] = tf.dy; fs[10 * n_slots] = tf.dz; fs[11 * n_slots] = tf.npx;
+                        fs[12 * n_slots] = tf.npy; fs[13 * n_slots] = tf.npz; fs[14 * n_slots] = tf.A;
+                    }
                 }
             }
             if (done) {
@@ -380,7 +444,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
             }
         }
     }
-    flush_counters(ctr, segs, exact, rounds_swept * ns * S);
+    flush_counters(ctr, segs, exact, rounds_swept * ((unsigned long long)ns + sv.n_tri_filter) * S);
     if (verify) {
         mism = wave_sum_u64(mism);
         if (lane == 0 && mism) atomicAdd(&ctr[0].pad_, mism);
@@ -523,11 +587,9 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
                               int n_cus, bool verify, hipStream_t stream)
 {
     const MixVariant &v = mix_variant();
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per launch: the attribute is per device and this call may come from any thread / device
         hipError_t e = hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const uint64_t slots_per_block = (uint64_t)v.threads * v.s;
     uint64_t want = (rv.n_rays + slots_per_block - 1) / slots_per_block;

@@ -130,6 +130,49 @@ def test_tie_break_first_object_wins(gpu):
         assert hip_render(gpu, o[::-1].copy(), 16, 16, kernel=kern, **cfg)[8, 8].tolist() == [0.0, 1.0, 0.0]
 
 
+def test_triangle_filter_classes_and_no_mismatch(gpu, oracle):
+    """The f32 triangle filter of the sweep kernel must never lose a hit the exact test reports -- including the
+    reference's phantom hits.  Scene: random triangles plus the special classes the upload treats separately:
+    axis-aligned triangles (pivot-row swaps -> "always candidate"), needle triangles (ill-conditioned projection),
+    degenerate ones ("can't handle LGS"), triangles behind / around the camera (undecided cull, |n.v0| <= 1), and a
+    triangle that the direction-based cull (triangle.rs:115) always rejects."""
+    import torch
+    from rust_raytracing_amd import scenes
+    base = scenes.light_every(scenes.compact(scenes.random_triangles(600, 4)), 3)
+    extra = np.zeros(9, dtype=gpu.OBJECT_DTYPE)
+    extra["kind"] = 2
+    geoms = [
+        (6, -1, -1, 6, 1, -1, 6, 0, 1),                 # in the plane x = 6: r.x = s.x = 0 -> row swaps
+        (5, -2, 0.5, 7, -2, 0.5, 6, 2, 0.5),            # in the plane z = 0.5
+        (4, 0, 0, 9, 1e-7, 0, 6.5, 5e-8, 3),            # needle in the xy projection (ill-conditioned)
+        (5, 0, 0, 6, 0, 0, 7, 0, 0),                    # collinear: degenerate
+        (0.3, -0.2, -0.2, 0.3, 0.2, -0.2, 0.3, 0, 0.3),  # just in front of the camera: |n.v0| < 1
+        (-3, -1, -1, -3, 1, -1, -3, 0, 1),              # entirely behind the camera: phantom hits (abs of the distance)
+        (7, 2, 2, 7.5, 2, 2.2, 7.2, 2.6, 2.1),
+        (3, 1, -1, 3, -1, -1, 3, 0, 1),                 # reversed winding of a facing triangle: always culled
+        (8, -3, 1, 8.5, -3.5, 1.5, 8.2, -2.6, 1.1),
+    ]
+    for k, g in enumerate(geoms):
+        extra[k]["geom"] = g
+        extra[k]["emission_color"] = (0.25 * (k + 1), 0.5, 1.0)
+        extra[k]["roughness"] = 1.0
+    objs = np.concatenate([base[:300], extra, base[300:]])
+    cfg = dict(rays_per_pixel=3, seed=13)
+    w, h = 72, 48
+    ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
+    assert ref.mean() > 0.01
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED):
+        assert max_abs_diff(hip_render(gpu, objs, w, h, kernel=kern, **cfg), ref) <= ATOL
+    hnd = hip_scene(gpu, objs, kernel=gpu.RTX_KERNEL_MIXED_VERIFY, **cfg).upload(0)
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    hnd.close()
+    assert st.filter_mismatches == 0 and st.segments == int(seg.sum())
+    assert max_abs_diff(buf.cpu().numpy(), ref) <= ATOL
+    # the filter did real work: far fewer exact tests than segments x triangles
+    assert st.exact_tests < 0.2 * st.segments * len(objs)
+
+
 def test_many_identical_spheres_first_wins(gpu, oracle):
     """24 copies of one sphere (all in one BVH leaf region, zero-extent centroid bounds) + 40 others: the copy that
     comes first in Scene.objects must win every tie (scene.rs:250), whatever order the BVH visits them in."""

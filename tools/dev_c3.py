@@ -1,0 +1,16 @@
+import sys, os, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch
+import rust_raytracing_amd as rtx
+from rust_raytracing_amd import scenes
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+w, h, spp = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (240, 135, 1)
+kernels = [int(k) for k in (sys.argv[5].split(",") if len(sys.argv) > 5 else ["2", "1"])]
+objs = scenes.random_triangles(n, 2)
+for kern in kernels:
+    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, kernel=kern), rtx.Camera(*scenes.CAMERA), objs).upload(0)
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    print("C3 n_tris", n, "%dx%dx%d" % (w, h, spp), "kernel", st.kernel, "trace %.2f ms" % st.trace_ms, "Mrays/s %.4f" % (w*h*spp/st.trace_ms/1e3),
+          "Msegments/s %.3f" % (st.segments/st.trace_ms/1e3), "seg/ray %.2f" % (st.segments/(w*h*spp)), "mean %.6f" % float(buf.mean()), flush=True)
+    hnd.close()
