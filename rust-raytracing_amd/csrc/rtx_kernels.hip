@@ -147,9 +147,12 @@ __device__ __forceinline__ f32x2 filter_disc2(const float4 A, const float4 B, co
 //   state  [12][n_slots] f64   ray.position, ray.direction, resulting_color, light_color  (ray.rs:4-21)
 //   fstate [16][n_slots] f32   the slot's sphere-filter (0-7) and triangle-filter (8-15) parameters
 //   istate [ 3][n_slots] u32   local pixel, batch-local sample, bounce count
+//   oflow  [24][n_slots] u32   candidates beyond the Q-entry LDS queue (a ray that collects more than Q + 24
+//                              candidates falls back to the exhaustive exact sweep)
 // Only a one-bit-per-slot `live` mask stays in registers across rounds, so the heavy f64 code (primary ray
 // generation, exact tests, shading) exists once and loops over the slots instead of being unrolled S times.
-constexpr size_t kSlotBytes = 12 * sizeof(double) + 16 * sizeof(float) + 3 * sizeof(uint32_t);
+constexpr int kOverflowQ = 24;             // candidates per slot beyond the LDS queue, kept in HBM (rare)
+constexpr size_t kSlotBytes = 12 * sizeof(double) + 16 * sizeof(float) + (3 + kOverflowQ) * sizeof(uint32_t);
 
 template <int S, int THREADS, int CHUNK, int Q, int WAVES_PER_EU>
 __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(const SceneView *__restrict__ svp,
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
     double *state = reinterpret_cast<double *>(slot_mem);
     float *fstate = reinterpret_cast<float *>(state + 12 * n_slots);
     uint32_t *istate = reinterpret_cast<uint32_t *>(fstate + 16 * n_slots);
+    uint32_t *oflow = istate + 3 * n_slots;
     const uint32_t ns = sv.n_spheres;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
@@ -297,7 +301,9 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                             const float dk = (k & 1) ? d[s][k >> 1].y : d[s][k >> 1].x;
                             if ((int)__float_as_uint(dk) >= 0) {
                                 if (cnt[s] < (uint32_t)Q) lds_q[((size_t)cnt[s] * S + s) * THREADS + tid] = c0 + j + k;
-                                cnt[s] += 1;                       // > Q marks overflow
+                                else if (cnt[s] < (uint32_t)(Q + kOverflowQ))
+                                    oflow[(size_t)(cnt[s] - Q) * n_slots + lane_gid + (uint64_t)s * n_lanes] = c0 + j + k;
+                                cnt[s] += 1;                       // > Q + kOverflowQ marks overflow
                             }
                         }
                     }
@@ -344,6 +350,9 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                                 if ((int)sg[s][k] >= 0) {
                                     if (cnt[s] < (uint32_t)Q)
                                         lds_q[((size_t)cnt[s] * S + s) * THREADS + tid] = 0x80000000u | sv.tri_fidx[c0 + j + k];
+                                    else if (cnt[s] < (uint32_t)(Q + kOverflowQ))
+                                        oflow[(size_t)(cnt[s] - Q) * n_slots + lane_gid + (uint64_t)s * n_lanes] =
+                                            0x80000000u | sv.tri_fidx[c0 + j + k];
                                     cnt[s] += 1;
                                 }
                             }
@@ -372,14 +381,15 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
             Hit h;
             hit_init(h);
             ++segs;
-            if (ncand > (uint32_t)Q) {
+            if (ncand > (uint32_t)(Q + kOverflowQ)) {
                 // more candidates than the queue holds (many shapes along one line, or a pass-all filter): exact sweep
                 closest_spheres_exact(sv, rx, h);
                 closest_tris_exact(sv, rx, h);
                 exact += ns + sv.n_tris;
             } else {
                 for (uint32_t k = 0; k < ncand; ++k) {
-                    const uint32_t idx = lds_q[((size_t)k * S + s) * THREADS + tid];
+                    const uint32_t idx = k < (uint32_t)Q ? lds_q[((size_t)k * S + s) * THREADS + tid]
+                                                         : oflow[(size_t)(k - Q) * n_slots + slot];
                     double t;
                     if (idx & 0x80000000u) {                                  // a triangle candidate
                         const uint32_t ti = idx & 0x7FFFFFFFu;

@@ -12,5 +12,5 @@ for kern in kernels:
     buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
     st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
     print("C3 n_tris", n, "%dx%dx%d" % (w, h, spp), "kernel", st.kernel, "trace %.2f ms" % st.trace_ms, "Mrays/s %.4f" % (w*h*spp/st.trace_ms/1e3),
-          "Msegments/s %.3f" % (st.segments/st.trace_ms/1e3), "seg/ray %.2f" % (st.segments/(w*h*spp)), "mean %.6f" % float(buf.mean()), flush=True)
+          "Msegments/s %.3f" % (st.segments/st.trace_ms/1e3), "seg/ray %.2f" % (st.segments/(w*h*spp)), "mean %.6f" % float(buf.mean()), "exact/seg %.1f" % (st.exact_tests/st.segments), "filter/seg %.0f" % (st.filter_tests/st.segments), flush=True)
     hnd.close()
