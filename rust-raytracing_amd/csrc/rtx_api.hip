@@ -316,7 +316,7 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     // flat BVH over the spheres (rtx_bvh.h); skipped for tiny or non-finite sphere sets and for trees deeper
     // than the traversal stack (the BVH kernel then sweeps the spheres exhaustively)
     BvhBuild bvh;
-    if (spheres.size() > (size_t)kBvhLeafSize) {
+    if (spheres.size() > 4) {
         std::vector<double> s4(4 * spheres.size());
         for (size_t k = 0; k < spheres.size(); ++k) {
             const RtxObject &o = scene->objects[sphere_id[k]];

@@ -172,11 +172,11 @@ __global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneVi
                         const uint32_t count = __float_as_uint(cb[c].w);
                         if (tc[c] < __builtin_inff() && count - 1u < (uint32_t)kBvhLeafSize) {
                             const uint32_t first = __float_as_uint(ca[c].w);
-                            if (qcnt + count > (uint32_t)kBvhQueue)
-                                flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                             for (uint32_t k = 0; k < count; ++k) {
                                 const float4 rec = sv.bvh_leaf_f32[first + k];
                                 if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
+                                    if (qcnt == (uint32_t)kBvhQueue)
+                                        flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                                     lds_q[qcnt][tid] = sv.bvh_prims[first + k];
                                     qcnt += 1;
                                 }
