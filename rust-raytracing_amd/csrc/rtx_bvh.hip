@@ -25,6 +25,10 @@ namespace rtx {
 namespace {
 
 constexpr int kBvhThreads = 256;
+#ifndef RTX_BVH_WPE
+#define RTX_BVH_WPE 4
+#endif
+constexpr int kBvhWavesPerSimd = RTX_BVH_WPE;     // = workgroups per CU (4 waves each)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kGrab = 512;            // rays a wave takes from the global queue per atomic
 
@@ -81,7 +85,7 @@ __device__ __forceinline__ void flush_candidates(const SceneView &sv, const RayX
 
 }  // namespace
 
-__global__ __launch_bounds__(kBvhThreads, 4) void trace_bvh_kernel(const SceneView *__restrict__ svp,
+__global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kernel(const SceneView *__restrict__ svp,
                                                                    const RowsView *__restrict__ rvp,
                                                                    double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                    unsigned long long *__restrict__ work_counter)
@@ -272,7 +276,7 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
 {
     (void)sv;
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
-    const uint64_t cap = (uint64_t)n_cus * 4;             // 16 waves per CU (4 per SIMD)
+    const uint64_t cap = (uint64_t)n_cus * kBvhWavesPerSimd;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(trace_bvh_kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters,
