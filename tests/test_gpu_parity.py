@@ -273,6 +273,68 @@ def test_edge_cases(gpu, oracle):
     assert ref.mean() > 0.01
 
 
+def _edge_scene(name):
+    """Scenes that push the conservative f32 machinery (filters, BVH boxes) to its guards; the f64 semantics of the
+    reference must survive every one of them."""
+    from rust_raytracing_amd import scenes
+    base = scenes.light_every(scenes.compact(scenes.random_spheres(48, 17)), 3)
+    cam = DEFAULT_CAM
+    cfg = dict(rays_per_pixel=2, seed=3)
+    if name == "negative_and_zero_radius":           # radius enters only as r*r (sphere.rs:24): -r behaves like r, 0 never hits
+        base["geom"][::5, 3] *= -1.0
+        base["geom"][1::7, 3] = 0.0
+    elif name == "huge_coordinates":                 # |c| ~ 1e15: f32 filter disabled (pass-all), BVH origin limit exceeded
+        base["geom"][:, :3] *= 1e15 / 8.0
+        base["geom"][:, 3] *= 1e15 / 8.0
+        cfg.update(focal_length=1e15, non_focal_offset=1e13, focal_offset=1e11)
+    elif name == "tiny_scale":                       # everything ~1e-13: filter error bound would underflow -> pass-all
+        base["geom"][:, :4] *= 1e-13
+        cfg.update(focal_length=1e-12, non_focal_offset=1e-15, focal_offset=1e-17)
+    elif name == "nan_and_inf_shapes":               # NaN centre: never hit; inf radius: discriminant inf -> t = -inf/NaN -> filtered
+        base["geom"][3, 0] = np.nan
+        base["geom"][9, 3] = np.inf
+        base["geom"][12, 1] = -np.inf
+    elif name == "unclamped_materials":              # negative / >1 base colours and roughness outside [0,1] are used as given
+        base["base_color"][::2] *= -1.5
+        base["base_color"][1::4] *= 3.0
+        base["roughness"][::3] = 1.7
+        base["roughness"][1::3] = 0.0
+    elif name == "fov_90_radians":                   # the reference's own default: Camera::new(.., 90f64) (scene.rs:90)
+        cam = (DEFAULT_CAM[0], DEFAULT_CAM[1], 90.0)
+    elif name == "camera_along_z":                   # direction parallel to z: right = fwd x (0,0,-1) = 0 -> NaN/zero basis (camera.rs:44)
+        cam = ((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 1.2)
+    elif name == "pinhole":                          # no jitter at all
+        cfg.update(focal_offset=0.0, non_focal_offset=0.0)
+    elif name == "zero_focal_length":
+        cfg.update(focal_length=0.0)
+    elif name == "deep_paths":
+        base["base_color"] = 0.95
+        base["emission_color"] *= 0.05
+        cfg.update(max_bounces=40, rays_per_pixel=1)
+    elif name == "camera_inside_a_big_sphere_and_far_plane":
+        extra = np.zeros(2, dtype=base.dtype)
+        extra[0]["kind"] = 0; extra[0]["geom"][:4] = (0, 0, 0, 50.0); extra[0]["emission_color"] = (1, 1, 1); extra[0]["roughness"] = 1
+        extra[1]["kind"] = 1; extra[1]["geom"][:6] = (0, 0, -3.0, 0, 0, 1); extra[1]["base_color"] = (.8, .8, .8); extra[1]["roughness"] = .4
+        base = np.concatenate([base, extra])
+    else:
+        raise KeyError(name)
+    return base, cam, cfg
+
+
+@pytest.mark.parametrize("name", ["negative_and_zero_radius", "huge_coordinates", "tiny_scale", "nan_and_inf_shapes",
+                                  "unclamped_materials", "fov_90_radians", "camera_along_z", "pinhole",
+                                  "zero_focal_length", "deep_paths", "camera_inside_a_big_sphere_and_far_plane"])
+def test_edge_scenes_match_oracle(gpu, oracle, name):
+    objs, cam, cfg = _edge_scene(name)
+    w, h = 40, 28
+    ref, seg = oracle_render(oracle, objs, w, h, cam=cam, want_segments=True, **cfg)
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
+        img = hip_render(gpu, objs, w, h, cam=cam, kernel=kern, **cfg)
+        assert np.array_equal(np.isnan(img), np.isnan(ref)), (name, kern)
+        scale = max(1.0, float(np.nanmax(np.abs(ref))) if np.isfinite(np.nanmax(np.abs(ref))) else 1.0)
+        assert max_abs_diff(img, ref) <= ATOL * scale, (name, kern)
+
+
 def test_unsupported_and_invalid_arguments(gpu):
     from rust_raytracing_amd import scenes
     bad = scenes.three_spheres().copy()
@@ -315,6 +377,32 @@ def test_cpp_host_api_example(gpu, oracle, tmp_path):
 
 
 # ---- BASELINE.json's full-size workload through size-independent properties ----------------------------------
+def test_c4_shaped_band_of_one_rank(gpu, oracle):
+    """BASELINE.json configs[3] is 3840x2160 over 8 GPUs: render the band rank 3 of 8 would own (270 interleaved rows,
+    2 spp here, scratch capped so that the samples are traced in batches) and check three of its rows against the oracle."""
+    import torch
+    from rust_raytracing_amd import scenes, tiles
+    objs = scenes.random_spheres(10000, 1)
+    w, h, world, rank = 3840, 2160, 8, 3
+    os.environ["RTX_HIP_SCRATCH_MB"] = "40"          # 270*3840*24 B = 24.9 MB per sample -> 1 sample per batch
+    try:
+        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*scenes.CAMERA), objs).upload(0)
+        rb, rs, n = tiles.rows_for_rank(h, rank, world)
+        band = tiles.alloc_band(h, w, world, "cuda:0")
+        st = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+        hnd.close()
+    finally:
+        del os.environ["RTX_HIP_SCRATCH_MB"]
+    assert st.trace_launches == 2 and st.primary_rays == n * w * 2
+    got = band[:n].cpu().numpy()
+    osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=2, seed=42)
+    for k in (0, 133, 269):
+        y = rb + k * rs
+        ref = oracle.render(osc, w, h, row_begin=y, row_stride=h)       # exactly one row
+        assert max_abs_diff(got[k], ref[y]) <= ATOL
+    assert got.mean() > 0.01
+
+
 def test_c2_full_size_properties(gpu, oracle):
     """10k spheres at 1920x1080 (1 spp here; the oracle cannot do this size in seconds):
     (1) a band of rows agrees with the oracle, (2) two renders are bit-identical (determinism),
