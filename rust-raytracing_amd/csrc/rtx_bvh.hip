@@ -70,13 +70,14 @@ __device__ __forceinline__ float round_up32(double best)
 constexpr int kBvhQueue = 8;               // candidate spheres a lane may hold between two exact passes
 
 // Exact f64 tests (sphere.rs:19-30) of the queued candidates; updates the winner and the pruning bound.
-__device__ __forceinline__ void flush_candidates(const SceneView &sv, const RayX &rx, const uint32_t *lds_q, uint32_t tid,
-                                                 uint32_t &qcnt, Hit &h, float &best_up, unsigned long long &exact)
+__device__ __forceinline__ void flush_candidates(const SphereX *__restrict__ spheres, const uint32_t *__restrict__ sphere_ids,
+                                                 const RayX &rx, const uint32_t *lds_q, uint32_t tid, uint32_t &qcnt, Hit &h,
+                                                 float &best_up, unsigned long long &exact)
 {
     for (uint32_t k = 0; k < qcnt; ++k) {
         const uint32_t idx = lds_q[(size_t)k * kBvhThreads + tid];
         double t;
-        if (sphere_distance(sv.spheres[idx], rx, &t)) hit_consider(h, t, sv.sphere_id[idx], 0, idx);
+        if (sphere_distance(spheres[idx], rx, &t)) hit_consider(h, t, sphere_ids[idx], 0, idx);
     }
     exact += qcnt;
     qcnt = 0;
@@ -88,15 +89,21 @@ __device__ __forceinline__ void flush_candidates(const SceneView &sv, const RayX
 __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kernel(const SceneView *__restrict__ svp,
                                                                    const RowsView *__restrict__ rvp,
                                                                    double *__restrict__ samples, Counters *__restrict__ ctr,
-                                                                   unsigned long long *__restrict__ work_counter)
+                                                                   unsigned long long *__restrict__ work_counter,
+                                                                   const float4 *__restrict__ nodes,
+                                                                   const float4 *__restrict__ leaf_f32,
+                                                                   const uint32_t *__restrict__ leaf_prims,
+                                                                   const SphereX *__restrict__ spheres,
+                                                                   const uint32_t *__restrict__ sphere_ids)
 {
+    // the hot arrays come in as kernel arguments (= known global address space -> global_load); a pointer read
+    // from the SceneView in memory would be `flat`, whose loads also tie up lgkmcnt together with the LDS stack
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
     __shared__ uint32_t lds_stack[kBvh4StackEntries][kBvhThreads];
     __shared__ uint32_t lds_q[kBvhQueue][kBvhThreads];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
     unsigned long long wave_next = 0, wave_end = 0;      // this wave's share of the ray queue (wave-uniform)
@@ -177,11 +184,11 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                         if (tc[c] < __builtin_inff() && count - 1u < (uint32_t)kBvhLeafSize) {
                             const uint32_t first = __float_as_uint(ca[c].w);
                             for (uint32_t k = 0; k < count; ++k) {
-                                const float4 rec = sv.bvh_leaf_f32[first + k];
+                                const float4 rec = leaf_f32[first + k];
                                 if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
                                     if (qcnt == (uint32_t)kBvhQueue)
-                                        flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
-                                    lds_q[qcnt][tid] = sv.bvh_prims[first + k];
+                                        flush_candidates(spheres, sphere_ids, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                                    lds_q[qcnt][tid] = leaf_prims[first + k];
                                     qcnt += 1;
                                 }
                             }
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                         }
                     }
                     step += 1;
-                    if ((step & 3u) == 0u) flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                    if ((step & 3u) == 0u) flush_candidates(spheres, sphere_ids, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                     // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
                     float key[4];
                     uint32_t lnk[4];
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                         node = lds_stack[sp][tid];      // its boxes are re-tested against the current bound when it is opened
                     }
                 }
-                flush_candidates(sv, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                flush_candidates(spheres, sphere_ids, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                 if (overflow) {                       // some subtree was dropped: every sphere gets the exact test
                     for (uint32_t k = 0; k < sv.n_spheres; ++k) {
                         double t;
@@ -274,13 +281,13 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
                             double *samples, Counters *counters, unsigned long long *work_counter, int n_cus,
                             hipStream_t stream)
 {
-    (void)sv;
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kBvhWavesPerSimd;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(trace_bvh_kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters,
-                       work_counter);
+                       work_counter, reinterpret_cast<const float4 *>(sv.bvh_nodes), sv.bvh_leaf_f32, sv.bvh_prims, sv.spheres,
+                       sv.sphere_id);
     return hipGetLastError();
 }
 
