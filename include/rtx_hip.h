@@ -50,9 +50,11 @@ enum {
                               produces the same bits as RTX_KERNEL_EXACT */
     RTX_KERNEL_MIXED_VERIFY = 3, /* debug: MIXED that also runs the exact sweep per segment and counts
                               disagreements in RtxStats.filter_mismatches (must stay 0) */
-    RTX_KERNEL_BVH = 4     /* spheres found by traversal of a flat BVH built at upload, exact f64
+    RTX_KERNEL_BVH = 4,    /* spheres found by traversal of a flat BVH built at upload, exact f64
                               leaf tests; planes and triangles tested exhaustively; same bits as RTX_KERNEL_EXACT.
                               RtxStats.filter_tests then counts BVH node visits */
+    RTX_KERNEL_POOL = 5    /* RTX_KERNEL_BVH's traversal with a wave-local pool of 256 rays: lanes pull the next ray as
+                              soon as their traversal ends instead of waiting for the wave's longest one; same bits */
 };
 
 /* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)

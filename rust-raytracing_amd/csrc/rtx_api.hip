@@ -111,7 +111,7 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
 
 int32_t check_config(const RtxConfig &cfg)
 {
-    if (cfg.kernel > RTX_KERNEL_BVH) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
+    if (cfg.kernel > RTX_KERNEL_POOL) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
     if (cfg.max_bounces == UINT64_MAX)       // max_bounces + 1 overflows in the reference (scene.rs:227)
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.max_bounces + 1 overflows");
     if (cfg.rays_per_pixel > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.rays_per_pixel exceeds 2^32-1");
@@ -441,6 +441,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (batch < spp) {
         if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
     }
+    if (kernel == RTX_KERNEL_POOL) {
+        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, pool_state_bytes(h->n_cus))) return rc;
+    }
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
@@ -473,6 +476,10 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
+        } else if (kernel == RTX_KERNEL_POOL) {
+            RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
+            RTX_HIP_CHECK(launch_trace_pool(h->d_sv, h->sv, h->d_rv, rv, h->samples, reinterpret_cast<char *>(h->state), h->counters,
+                                            h->work_counter, h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter, h->n_cus, stream));

@@ -19,69 +19,21 @@
 // Bound: latency / L2 bandwidth of the node fetches; algorithmic bytes per segment = box_tests * 32 +
 // leaf_filter_tests * 16 + exact_tests * 32 (BVH config), all counted by the kernel.
 #include "rtx_launch.h"
+#include "rtx_traverse.h"
 
 namespace rtx {
 
 namespace {
 
-constexpr int kBvhThreads = 256;
 #ifndef RTX_BVH_WPE
 #define RTX_BVH_WPE 4
 #endif
 constexpr int kBvhWavesPerSimd = RTX_BVH_WPE;     // = workgroups per CU (4 waves each)
-constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kGrab = 512;            // rays a wave takes from the global queue per atomic
 
 __device__ __forceinline__ uint32_t bvh_mbcnt(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-struct Ray32 { float ox, oy, oz, ix, iy, iz; };
-
-// f32 slab test; returns a lower bound of the entry distance, or +inf on a certain miss.
-//   t = fl(fl(b - fl(o)) * fl(1/d)): the origin rounding is covered by the boxes' absolute padding (rtx_bvh.h);
-//   the remaining roundings are a relative error < 2^-22 on every t, so the interval is widened by 2^-21 |t|.
-// fminf/fmaxf return the non-NaN operand (0 * inf: origin on a slab of an axis-parallel ray), which only widens
-// the interval; an infinite tn/tf of a ray that runs outside a slab turns the widened bound into NaN and the
-// comparison into "miss", which is the right answer.
-__device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, const Ray32 &r, float best_up)
-{
-    const float x0 = (lo.x - r.ox) * r.ix, x1 = (hi.x - r.ox) * r.ix;
-    const float y0 = (lo.y - r.oy) * r.iy, y1 = (hi.y - r.oy) * r.iy;
-    const float z0 = (lo.z - r.oz) * r.iz, z1 = (hi.z - r.oz) * r.iz;
-    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    const float eps = 4.76837158e-7f;                                   // 2^-21
-    const float tn_lo = __builtin_fmaf(-eps, __builtin_fabsf(tn), tn);
-    const float tf_hi = __builtin_fmaf(eps, __builtin_fabsf(tf), tf);
-    const bool hit = (tn_lo <= tf_hi) && (tf_hi >= 0.0f) && (tn_lo <= best_up);
-    return hit ? tn_lo : __builtin_inff();      // the widened (conservative) entry distance
-}
-
-// best (f64) rounded UP to f32 for the pruning comparison
-__device__ __forceinline__ float round_up32(double best)
-{
-    float b = (float)best;
-    if ((double)b < best) b = __uint_as_float(__float_as_uint(b) + (b >= 0.0f ? 1u : 0xFFFFFFFFu));
-    return b;
-}
-
-constexpr int kBvhQueue = 8;               // candidate spheres a lane may hold between two exact passes
-
-// Exact f64 tests (sphere.rs:19-30) of the queued candidates; updates the winner and the pruning bound.
-__device__ __forceinline__ void flush_candidates(const SphereX *__restrict__ spheres, const uint32_t *__restrict__ sphere_ids,
-                                                 const RayX &rx, const uint32_t *lds_q, uint32_t tid, uint32_t &qcnt, Hit &h,
-                                                 float &best_up, unsigned long long &exact)
-{
-    for (uint32_t k = 0; k < qcnt; ++k) {
-        const uint32_t idx = lds_q[(size_t)k * kBvhThreads + tid];
-        double t;
-        if (sphere_distance(spheres[idx], rx, &t)) hit_consider(h, t, sphere_ids[idx], 0, idx);
-    }
-    exact += qcnt;
-    qcnt = 0;
-    if (h.id != kNone) best_up = round_up32(h.t);
 }
 
 }  // namespace
@@ -112,6 +64,9 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
     RayState r;
     uint32_t pl = 0, smp = 0;
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
+#ifdef RTX_BVH_STATS
+    unsigned long long wave_steps = 0;      // diagnostic: traversal-loop iterations of the wave (reported via exact_tests)
+#endif
 
     for (;;) {
         // ---- hand rays to idle lanes: ballot + prefix sum over the wave's local range, one atomic per 512 rays
@@ -166,6 +121,9 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                 bool overflow = false;
                 uint32_t node = 0;                       // wide node 0 is the root
                 while (node != kNone) {
+#ifdef RTX_BVH_STATS
+                    { const unsigned long long am = __ballot(true); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) wave_steps += 1; }
+#endif
                     // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
                     const float4 *np = nodes + 8 * (size_t)node;
                     float4 ca[4], cb[4];
@@ -260,6 +218,9 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
         }
     }
     // counters: segments, exact f64 shape tests, box tests + leaf filter tests (reported through filter_tests)
+#ifdef RTX_BVH_STATS
+    exact = wave_steps;
+#endif
     unsigned long long filt = box_tests + leaf_filters;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -25,6 +25,13 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
                             double *samples, Counters *counters, unsigned long long *work_counter, int n_cus,
                             hipStream_t stream);
 
+// POOL kernel: the BVH traversal with a wave-local pool of 256 rays (state in HBM SoA, pool_state_bytes(n_cus) bytes)
+// from which lanes pull the next ray as soon as their traversal ends.
+size_t pool_state_bytes(int n_cus);
+hipError_t launch_trace_pool(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                             double *samples, char *pool_mem, Counters *counters, unsigned long long *work_counter, int n_cus,
+                             hipStream_t stream);
+
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
 // sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.
 hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,

@@ -32,7 +32,7 @@ def gpu(rtx):
 
 
 def _kernels(rtx):
-    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH]
+    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_POOL]
 
 
 # ---- device arithmetic ---------------------------------------------------------------------------
@@ -73,7 +73,7 @@ def test_hip_matches_oracle_seeded(gpu, oracle, case):
         "tris": (scenes.light_every(scenes.compact(scenes.random_triangles(400, 5)), 3), 48, 32, dict(rays_per_pixel=3, seed=8)),
     }[case]
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_POOL):
         scene = hip_scene(gpu, objs, kernel=kern, **cfg)
         img = scene.render(w, h)
         assert max_abs_diff(img, ref) <= ATOL, (case, kern)
@@ -328,7 +328,7 @@ def test_edge_scenes_match_oracle(gpu, oracle, name):
     objs, cam, cfg = _edge_scene(name)
     w, h = 40, 28
     ref, seg = oracle_render(oracle, objs, w, h, cam=cam, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_POOL, gpu.RTX_KERNEL_AUTO):
         img = hip_render(gpu, objs, w, h, cam=cam, kernel=kern, **cfg)
         assert np.array_equal(np.isnan(img), np.isnan(ref)), (name, kern)
         scale = max(1.0, float(np.nanmax(np.abs(ref))) if np.isfinite(np.nanmax(np.abs(ref))) else 1.0)
