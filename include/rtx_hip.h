@@ -142,6 +142,11 @@ int32_t rtx_scene_free(RtxSceneHandle scene);
 /* Replace the Config of an uploaded scene (rays_per_pixel, seed, kernel, ...). */
 int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config);
 
+/* Replace the Camera of an uploaded scene without re-uploading the objects (the reference's analogue is
+ * Scene.camera being a pub field, scene.rs:82, with Camera::set_direction camera.rs:35-40).  Only fov, position and
+ * to_world_space are read by render. */
+int32_t rtx_scene_set_camera(RtxSceneHandle scene, const RtxCamera *camera);
+
 /*
  * Renders image rows row_begin, row_begin+row_stride, ... (n_rows of them, all < height) of the
  * width x height image into d_out_rgb, a DEVICE buffer of n_rows*width*3 doubles (row k of the

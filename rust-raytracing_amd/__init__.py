@@ -335,6 +335,10 @@ class SceneHandle:
         c = config.to_c()
         abi.check(self._lib.rtx_scene_set_config(self._h, C.byref(c)))
 
+    def set_camera(self, camera):
+        c = camera.to_c()
+        abi.check(self._lib.rtx_scene_set_camera(self._h, C.byref(c)))
+
     def render_rows(self, width, height, row_begin, row_stride, n_rows, d_out_ptr, stream=None, want_stats=True):
         """d_out_ptr: device address of n_rows*width*3 doubles (e.g. a torch tensor's data_ptr())."""
         stats = abi.RtxStats()

@@ -372,6 +372,18 @@ int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config)
     return RTX_OK;
 }
 
+int32_t rtx_scene_set_camera(RtxSceneHandle scene, const RtxCamera *camera)
+{
+    if (!scene || !camera) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_set_camera: null argument");
+    scene->cam = *camera;
+    scene->sv.cam_pos = mk(camera->position[0], camera->position[1], camera->position[2]);
+    scene->sv.to_world_x = mk(camera->to_world_space[0], camera->to_world_space[1], camera->to_world_space[2]);
+    scene->sv.to_world_y = mk(camera->to_world_space[3], camera->to_world_space[4], camera->to_world_space[5]);
+    scene->sv.to_world_z = mk(camera->to_world_space[6], camera->to_world_space[7], camera->to_world_space[8]);
+    scene->sv_dirty = true;                   // the trig tables are keyed on cam.fov and rebuilt when it changed
+    return RTX_OK;
+}
+
 int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_stride,
                         uint32_t n_rows, double *d_out_rgb, void *stream_, RtxStats *stats)
 {

@@ -229,6 +229,34 @@ def test_partition_by_rows_is_invisible(gpu):
     assert np.array_equal(got, full)
 
 
+def test_resident_scene_config_and_camera_updates(gpu, oracle):
+    """Split form of the C ABI: one upload, then rtx_scene_set_config / rtx_scene_set_camera between renders
+    (change camera / settings without re-uploading the objects)."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.light_every(scenes.compact(scenes.random_spheres(200, 31)), 4)
+    w, h = 56, 40
+    cfg0 = gpu.Config(rays_per_pixel=2, seed=1)
+    cam0 = gpu.Camera(*scenes.CAMERA)
+    hnd = gpu.Scene.from_packed(cfg0, cam0, objs).upload(0)
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    steps = [
+        (cfg0, scenes.CAMERA),
+        (cfg0.with_seed(9).with_rays_per_pixel(3), scenes.CAMERA),
+        (cfg0.with_seed(9).with_rays_per_pixel(3), ((0.5, -1.0, 0.3), (1.0, 0.2, -0.1), 1.0)),          # moved camera, new fov
+        (cfg0.with_max_bounces(1).with_kernel(gpu.RTX_KERNEL_MIXED), ((0.5, -1.0, 0.3), (1.0, 0.2, -0.1), 1.0)),
+        (cfg0, scenes.CAMERA),                                                                           # and back
+    ]
+    for cfg, cam in steps:
+        hnd.set_config(cfg)
+        hnd.set_camera(gpu.Camera(*cam))
+        hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        ref = oracle_render(oracle, objs, w, h, cam=cam, rays_per_pixel=cfg.rays_per_pixel, seed=cfg.seed,
+                            max_bounces=cfg.max_bounces)
+        assert max_abs_diff(buf.cpu().numpy(), ref) <= ATOL
+    hnd.close()
+
+
 def test_sample_batching_keeps_the_left_fold(gpu, oracle, monkeypatch):
     """With scratch capped, samples are traced in several batches; the fold order (iter_ops.rs:4-8) must not change."""
     from rust_raytracing_amd import scenes
