@@ -43,18 +43,18 @@ enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_TRIANGLE = 2 };
 
 /* Kernel selection (RtxConfig.kernel). */
 enum {
-    RTX_KERNEL_AUTO  = 0,  /* RTX_KERNEL_BVH when the scene has more than 4 (finite) spheres, else RTX_KERNEL_MIXED;
-                              all kernels produce the same bits, AUTO picks the fastest */
+    RTX_KERNEL_AUTO  = 0,  /* RTX_KERNEL_BVH when a tree was built at upload (more than 4 finite spheres and/or more than
+                              4 triangles with an (x, y) footprint) and at most 64 spheres/triangles stay outside it,
+                              else RTX_KERNEL_MIXED; all kernels produce the same bits, AUTO picks the fastest */
     RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
     RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
                               produces the same bits as RTX_KERNEL_EXACT */
     RTX_KERNEL_MIXED_VERIFY = 3, /* debug: MIXED that also runs the exact sweep per segment and counts
                               disagreements in RtxStats.filter_mismatches (must stay 0) */
-    RTX_KERNEL_BVH = 4,    /* spheres found by traversal of a flat BVH built at upload, exact f64
-                              leaf tests; planes and triangles tested exhaustively; same bits as RTX_KERNEL_EXACT.
-                              RtxStats.filter_tests then counts BVH node visits */
-    RTX_KERNEL_POOL = 5    /* RTX_KERNEL_BVH's traversal with a wave-local pool of 256 rays: lanes pull the next ray as
-                              soon as their traversal ends instead of waiting for the wave's longest one; same bits */
+    RTX_KERNEL_BVH = 4     /* spheres and triangles found by traversal of a flat BVH built at upload (SURVEY 8f N2:
+                              3-D sphere boxes; (x, y) footprints for triangles, which keeps the reference's phantom
+                              hits), exact f64 leaf tests; planes and shapes outside the tree tested for every
+                              segment; same bits as RTX_KERNEL_EXACT.  RtxStats.box_tests counts child boxes tested */
 };
 
 /* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)

@@ -56,6 +56,14 @@ size_t scratch_cap_bytes()
     return mb << 20;
 }
 
+uint32_t tri_leaf_size()                 // triangles per BVH leaf; RTX_HIP_TRI_LEAF is a tuning knob (1..8)
+{
+    const char *e = std::getenv("RTX_HIP_TRI_LEAF");
+    long v = 2;
+    if (e && *e) v = std::strtol(e, nullptr, 10);
+    return (uint32_t)(v < 1 ? 1 : (v > kBvhTriLeafMax ? kBvhTriLeafMax : v));
+}
+
 }  // namespace
 
 struct RtxSceneHandle_ {
@@ -111,7 +119,7 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
 
 int32_t check_config(const RtxConfig &cfg)
 {
-    if (cfg.kernel > RTX_KERNEL_POOL) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
+    if (cfg.kernel > RTX_KERNEL_BVH) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
     if (cfg.max_bounces == UINT64_MAX)       // max_bounces + 1 overflows in the reference (scene.rs:227)
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.max_bounces + 1 overflows");
     if (cfg.rays_per_pixel > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.rays_per_pixel exceeds 2^32-1");
@@ -266,9 +274,11 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
         sph32[k] = make_float4(fx[k], fx[k + 1], fy[k], fy[k + 1]);
         sph32[k + 1] = make_float4(fz[k], fz[k + 1], fw[k], fw[k + 1]);
     }
-    // triangle filter records (rtx_device.h "triangle filter"): only triangles that can be hit at all
-    std::vector<float4> tri32;
-    std::vector<uint32_t> tri_fidx;
+    // triangle filter records (rtx_device.h "triangle filter"): only triangles that can be hit at all.  The "plain"
+    // ones (pivot rows x, y; well-conditioned projection) also get a footprint box for the tree (rtx_bvh.h).
+    struct TriRec { float4 A, B; uint32_t tri; };
+    std::vector<TriRec> plain_recs, always_recs;
+    std::vector<BvhBox> tri_boxes;
     double tri_extent = 0.0;
     for (size_t k = 0; k < tris.size(); ++k) {
         const TriX &t = tris[k];
@@ -284,22 +294,50 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
         const double rx = v[1][0] - v[0][0], ry = v[1][1] - v[0][1], sx = v[2][0] - v[0][0], sy = v[2][1] - v[0][1];
         const double det = rx * sy - ry * sx;
         const bool rows_xy = (t.i == 0 && t.j == 1);
-        const bool plain = finite && rows_xy && std::fabs(det) > 1e-6 * std::hypot(rx, ry) * std::hypot(sx, sy);
-        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = make_float4(0.f, 0.f, 0.f, 0.f);      // "always a candidate"
+        BvhBox fp;
+        const bool plain = finite && rows_xy && std::fabs(det) > 1e-6 * std::hypot(rx, ry) * std::hypot(sx, sy) &&
+                           triangle_footprint(o.geom, fp);
+        TriRec rec;
+        rec.A = make_float4(0.f, 0.f, 0.f, 0.f);                       // "always a candidate"
+        rec.B = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec.tri = (uint32_t)k;
         if (plain) {
             const double xlo = std::fmin(v[0][0], std::fmin(v[1][0], v[2][0])), xhi = std::fmax(v[0][0], std::fmax(v[1][0], v[2][0]));
             const double ylo = std::fmin(v[0][1], std::fmin(v[1][1], v[2][1])), yhi = std::fmax(v[0][1], std::fmax(v[1][1], v[2][1]));
             const double kc = t.n.x * v[0][0] + t.n.y * v[0][1] + t.n.z * v[0][2];
             const double grow = 1.0 + 1.0 / 1048576.0;
-            A = make_float4((float)t.n.x, (float)t.n.y, (float)t.n.z, (float)kc);
-            B = make_float4((float)(0.5 * (xlo + xhi)), (float)(0.5 * (ylo + yhi)),
-                            round_up_f32(0.5 * (xhi - xlo) * grow + 1e-30), round_up_f32(0.5 * (yhi - ylo) * grow + 1e-30));
+            rec.A = make_float4((float)t.n.x, (float)t.n.y, (float)t.n.z, (float)kc);
+            rec.B = make_float4((float)(0.5 * (xlo + xhi)), (float)(0.5 * (ylo + yhi)),
+                                round_up_f32(0.5 * (xhi - xlo) * grow + 1e-30), round_up_f32(0.5 * (yhi - ylo) * grow + 1e-30));
             for (int c = 0; c < 9; ++c) tri_extent = std::fmax(tri_extent, std::fabs(v[c / 3][c % 3]));
+            plain_recs.push_back(rec);
+            tri_boxes.push_back(fp);
+        } else {
+            always_recs.push_back(rec);
         }
-        tri32.push_back(A);
-        tri32.push_back(B);
-        tri_fidx.push_back((uint32_t)k);
     }
+
+    // flat BVH over the sphere boxes and the plain triangles' footprints (rtx_bvh.h); a kind with fewer than 5
+    // members, or non-finite spheres, gets no sub-tree (the BVH kernel then tests those shapes for every segment)
+    std::vector<BvhBox> sphere_boxes(spheres.size());
+    bool spheres_finite = true;
+    for (size_t k = 0; k < spheres.size() && spheres_finite; ++k)
+        spheres_finite = sphere_box(scene->objects[sphere_id[k]].geom, sphere_boxes[k]);
+    if (!spheres_finite) sphere_boxes.clear();
+    BvhBuild bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size());
+    Bvh4Build bvh4 = collapse_to_bvh4(bvh);
+
+    // records in leaf order first (a triangle leaf's link indexes them), then the always-candidates
+    std::vector<float4> tri32;
+    std::vector<uint32_t> tri_fidx;
+    tri32.reserve(2 * (plain_recs.size() + always_recs.size()));
+    if (bvh.has_tris) {
+        for (uint32_t idx : bvh.tri_order) { const TriRec &r = plain_recs[idx]; tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
+    } else {
+        for (const TriRec &r : plain_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
+    }
+    h->sv.n_tri_tree = bvh.has_tris ? (uint32_t)plain_recs.size() : 0u;
+    for (const TriRec &r : always_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
     h->sv.n_tri_filter = (uint32_t)tri_fidx.size();
     h->sv.tri_extent = tri_extent;
     h->sv.n_objects = (uint32_t)n;
@@ -313,21 +351,10 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
     h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
 
-    // flat BVH over the spheres (rtx_bvh.h); skipped for tiny or non-finite sphere sets and for trees deeper
-    // than the traversal stack (the BVH kernel then sweeps the spheres exhaustively)
-    BvhBuild bvh;
-    if (spheres.size() > 4) {
-        std::vector<double> s4(4 * spheres.size());
-        for (size_t k = 0; k < spheres.size(); ++k) {
-            const RtxObject &o = scene->objects[sphere_id[k]];
-            for (int c = 0; c < 4; ++c) s4[4 * k + c] = o.geom[c];
-        }
-        bvh = build_sphere_bvh(s4.data(), (uint32_t)spheres.size());
-    }
-    Bvh4Build bvh4 = collapse_to_bvh4(bvh);
     h->sv.n_bvh_nodes = (uint32_t)bvh4.nodes.size();
     h->sv.bvh_depth = (uint32_t)bvh4.depth;
     h->sv.bvh_origin_limit = (float)bvh.origin_limit;
+    h->sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);
     std::vector<float4> leaf32(bvh.prims.size());
     for (size_t k = 0; k < bvh.prims.size(); ++k) {
         const uint32_t p = bvh.prims[k];
@@ -400,9 +427,11 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     const uint32_t npix = n_rows * width;
     const uint64_t spp = h->cfg.rays_per_pixel;
-    // AUTO: the BVH kernel when a sphere BVH was built at upload (> 4 finite spheres) and the scene has few triangles
-    // (that kernel tests triangles exhaustively in f64), else the LDS sweep with its sphere and triangle filters
-    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? (h->sv.n_bvh_nodes != 0 && h->sv.n_tri_filter <= 32 ? RTX_KERNEL_BVH : RTX_KERNEL_MIXED)
+    // AUTO: the BVH kernel when a tree was built at upload and few shapes stay outside it (that kernel tests those
+    // for every segment in f64), else the LDS sweep with its sphere and triangle filters
+    const uint64_t outside_tree = ((h->sv.bvh_flags & 1u) ? 0u : h->sv.n_spheres) +
+                                  (uint64_t)(h->sv.n_tri_filter - h->sv.n_tri_tree);
+    const uint32_t kernel = h->cfg.kernel == RTX_KERNEL_AUTO ? (h->sv.n_bvh_nodes != 0 && outside_tree <= 64 ? RTX_KERNEL_BVH : RTX_KERNEL_MIXED)
                                                               : h->cfg.kernel;
 
     // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row
@@ -453,8 +482,8 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (batch < spp) {
         if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
     }
-    if (kernel == RTX_KERNEL_POOL) {
-        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, pool_state_bytes(h->n_cus))) return rc;
+    if (kernel == RTX_KERNEL_BVH) {
+        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, bvh_spill_bytes(h->sv, h->n_cus))) return rc;
     }
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
@@ -488,13 +517,10 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
-        } else if (kernel == RTX_KERNEL_POOL) {
-            RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            RTX_HIP_CHECK(launch_trace_pool(h->d_sv, h->sv, h->d_rv, rv, h->samples, reinterpret_cast<char *>(h->state), h->counters,
-                                            h->work_counter, h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter, h->n_cus, stream));
+            RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                           reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,

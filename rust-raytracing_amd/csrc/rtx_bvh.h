@@ -1,15 +1,28 @@
-// rtx_bvh.h -- flat BVH over the scene's spheres: host builder + node layout.
+// rtx_bvh.h -- flat BVH over the scene's spheres and triangles: host builder + node layout.
 //
-// The reference walks every object per segment (scene.rs:243-251).  For spheres the same winner can be found
-// by visiting only the boxes a ray touches: a sphere the reference reports (near root, is_normal, > 0) is a real
-// intersection with t > 0 (sphere.rs:19-30; SURVEY H2 "spheres are BVH-safe"), so it lies inside the sphere's
-// (inflated) bounding box, which lies inside every ancestor's box.  The leaves run the SAME exact f64 test as
-// the brute-force kernels and the winner is chosen with the same (t, scene index) order, so the image has the
-// same bits.  Triangles are NOT put in the BVH: the reference's Triangle::distance reports hits for rays that
-// miss the triangle's box (phantom hits), so any spatial culling would change the image.
+// The reference walks every object per segment (scene.rs:243-251).  The same winner can be found by visiting
+// only the boxes a ray touches, as long as a box can never hide a hit the reference would report:
+//
+//  * Spheres.  A sphere the reference reports (near root, is_normal, > 0) is a real intersection with t > 0
+//    (sphere.rs:19-30; SURVEY H2 "spheres are BVH-safe"), so the hit point lies inside the sphere's (inflated) 3-D
+//    bounding box, which lies inside every ancestor's box.
+//  * Triangles.  Triangle::distance (triangle.rs:108-127) takes |t| of the plane distance and Triangle::contains
+//    (triangle.rs:37-101) solves only two rows of the system, so it reports "phantom" hits for rays that miss the
+//    triangle's 3-D box -- a 3-D BVH would change the image.  But every hit it reports, phantom or
+//    not, is decided at the point q = p + dir * |t| with |t| >= 0, and (for the x, y pivot rows) only by q's
+//    (x, y) projection being inside the projected triangle.  Hence: hit at distance |t|  =>  the ray, walked
+//    FORWARD from its origin for a length |t|, is above the triangle's (x, y) footprint.  Triangles therefore go
+//    into the tree with their (x, y) footprint rectangle and an unbounded z interval: the slab test prunes in
+//    two dimensions, and entry-distance pruning against the best hit stays valid.  Triangles whose elimination
+//    pivots are not rows (x, y), or whose projection is ill-conditioned, stay outside the tree and are tested for
+//    every segment (rtx_api.hip).
+//
+// The leaves run the SAME exact f64 tests as the brute-force kernels and the winner is chosen with the same
+// (t, scene index) order, so the image has the same bits.
 //
 // The reference's own GPU path already attaches a box to each shape -- sphere: position -/+ radius
-// (object/sphere.rs:82-86), planes unbounded (plane.rs:83-85) -- the builder uses that box formula.
+// (object/sphere.rs:82-86), triangle: min/max of the vertices (triangle.rs:190-194), planes unbounded
+// (plane.rs:83-85) -- the builder uses those box formulas (the triangle's restricted to x, y).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,11 +36,11 @@
 
 namespace rtx {
 
-// 32-byte node of the flat array (depth-first order: the left child of node i is node i + 1).
+// 32-byte node of the flat binary tree (depth-first order: the left child of node i is node i + 1).
 //   interior: count == 0, link = index of the right child
-//   leaf:     count  > 0, link = first entry in bvh_prims[], count entries
-// Boxes are f32, rounded OUTWARD from the f64 sphere bounds and inflated (relative 2^-20 of the sphere's reach plus
-// BvhBuild::abs_pad), so that the f32 slab test of the traversal can never exclude a sphere the exact f64 test
+//   leaf:     count  > 0, link = first leaf entry, (count & 0xFFFF) entries; kBvhTriLeaf set = triangle entries
+// Boxes are f32, rounded OUTWARD from the f64 bounds and inflated (relative 2^-20 of the shape's reach plus
+// BvhBuild::abs_pad), so that the f32 slab test of the traversal can never exclude a shape the exact f64 test
 // would accept.
 struct BvhNode {
     float lo[3];
@@ -37,18 +50,22 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 
+constexpr uint32_t kBvhTriLeaf = 0x10000u;  // flag in a leaf's count: the entries are triangle filter records
 constexpr int kBvhLeafSize = 1;            // spheres per leaf; measured on C2 at 16 spp: leaf 1/2/4/8/16 = 1123/999/919/840/668 Mrays/s
                                            // (storing the sphere's filter record in place of the leaf box was slower: 1057)
-constexpr int kBvhMaxDepth = 30;          // traversal stack entries per ray
+constexpr int kBvhTriLeafMax = 8;          // upper bound of triangles per leaf (the build's leaf size is a parameter)
+
+struct BvhBox { double lo[3], hi[3]; };    // hi[2] = -lo[2] = inf for a triangle footprint
 
 struct BvhBuild {
     std::vector<BvhNode> nodes;
     std::vector<uint32_t> prims;          // local sphere indices, leaf-contiguous
-    int depth = 0;
+    std::vector<uint32_t> tri_order;      // triangle (footprint) indices, leaf-contiguous
+    bool has_spheres = false, has_tris = false;
     // The traversal's slab test runs in f32: t = fl(fl(b - fl(o)) * fl(1/d)).  Rounding the origin shifts both faces
     // of an axis by at most 2^-24 |o|, every other rounding is a relative error <= 2^-22 on t (handled in the test).
     // Every box is therefore also inflated by `abs_pad` >= 2^-22 * origin_limit on each side; rays whose origin lies
-    // outside |o|_inf <= origin_limit do not use the tree (they sweep the spheres exhaustively).
+    // outside |o|_inf <= origin_limit do not use the tree (they sweep the shapes exhaustively).
     double origin_limit = 0.0;
     double abs_pad = 0.0;
 };
@@ -67,54 +84,64 @@ inline float round_up_f32(double x)
     return f;
 }
 
-// spheres: n x {cx, cy, cz, r} (f64).  Returns an empty build when any sphere is not finite (the caller then
-// does not offer the BVH kernel for this scene).
-inline BvhBuild build_sphere_bvh(const double *spheres4, uint32_t n)
+// object/sphere.rs:82-86: position -/+ radius, inflated by 2^-20 relative + a denormal-safe absolute term.
+// Returns false when the sphere is not finite.
+inline bool sphere_box(const double s[4], BvhBox &b)
 {
-    BvhBuild out;
-    if (n == 0) return out;
-    struct Box { double lo[3], hi[3]; };
-    std::vector<Box> box(n);
-    std::vector<double> cen(3 * (size_t)n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const double *s = spheres4 + 4 * (size_t)i;
-        const double r = std::fabs(s[3]);
-        for (int a = 0; a < 3; ++a) {
-            if (!std::isfinite(s[a]) || !std::isfinite(r)) return BvhBuild();
-            // object/sphere.rs:82-86: position -/+ radius, inflated by 2^-20 relative + a denormal-safe absolute term
-            const double pad = (std::fabs(s[a]) + r) * (1.0 / 1048576.0) + 1e-300;
-            box[i].lo[a] = s[a] - r - pad;
-            box[i].hi[a] = s[a] + r + pad;
-            cen[3 * (size_t)i + a] = s[a];
-        }
+    const double r = std::fabs(s[3]);
+    for (int a = 0; a < 3; ++a) {
+        if (!std::isfinite(s[a]) || !std::isfinite(r)) return false;
+        const double pad = (std::fabs(s[a]) + r) * (1.0 / 1048576.0) + 1e-300;
+        b.lo[a] = s[a] - r - pad;
+        b.hi[a] = s[a] + r + pad;
     }
-    double scale = 0.0;
+    return true;
+}
+
+// triangle.rs:190-194 restricted to (x, y): min/max of the vertices, same inflation; z unbounded (see the top).
+inline bool triangle_footprint(const double v[9], BvhBox &b)
+{
+    for (int a = 0; a < 2; ++a) {
+        const double x0 = v[a], x1 = v[3 + a], x2 = v[6 + a];
+        if (!std::isfinite(x0) || !std::isfinite(x1) || !std::isfinite(x2)) return false;
+        const double lo = std::fmin(x0, std::fmin(x1, x2)), hi = std::fmax(x0, std::fmax(x1, x2));
+        const double pad = std::fmax(std::fabs(lo), std::fabs(hi)) * (1.0 / 1048576.0) + 1e-300;
+        b.lo[a] = lo - pad;
+        b.hi[a] = hi + pad;
+    }
+    b.lo[2] = -INFINITY;
+    b.hi[2] = INFINITY;
+    return true;
+}
+
+// Appends the binary tree over `box` to out.nodes (its root is the first node appended) and the leaf order to
+// `order`.  Median split of the box centres along the widest of the first `dims` axes: balanced, depth <=
+// ceil(log2(n / leaf)) + 1.
+inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t leaf_size, uint32_t leaf_flag,
+                            BvhBuild &out, std::vector<uint32_t> &order_out)
+{
+    const uint32_t n = (uint32_t)box.size();
+    std::vector<double> cen((size_t)dims * n);
     for (uint32_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(box[i].lo[a]), std::fabs(box[i].hi[a])));
-    out.origin_limit = 4.0 * scale + 1.0;
-    out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
-    if (!(out.origin_limit < 1.0e30)) return BvhBuild();
+        for (int a = 0; a < dims; ++a) cen[(size_t)dims * i + a] = 0.5 * (box[i].lo[a] + box[i].hi[a]);
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
-    out.nodes.reserve(2 * (size_t)n / kBvhLeafSize + 2);
-
-    struct Task { uint32_t begin, end; int parent; int depth; };     // parent < 0: root; parent's link is set when the right child is emitted
+    struct Task { uint32_t begin, end; int parent; };     // parent < 0: nothing to patch; else parent's link is set when this (right) child is emitted
     std::vector<Task> todo;
-    todo.push_back({0u, n, -1, 1});
+    todo.push_back({0u, n, -1});
     while (!todo.empty()) {
         const Task t = todo.back();
         todo.pop_back();
         const uint32_t me = (uint32_t)out.nodes.size();
         if (t.parent >= 0) out.nodes[(size_t)t.parent].link = me;   // we are a RIGHT child (left children are emitted right after their parent)
-        out.depth = std::max(out.depth, t.depth);
-        Box b;
+        BvhBox b;
         double clo[3], chi[3];
         for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; clo[a] = INFINITY; chi[a] = -INFINITY; }
         for (uint32_t k = t.begin; k < t.end; ++k) {
             const uint32_t i = order[k];
-            for (int a = 0; a < 3; ++a) {
-                b.lo[a] = std::min(b.lo[a], box[i].lo[a]); b.hi[a] = std::max(b.hi[a], box[i].hi[a]);
-                clo[a] = std::min(clo[a], cen[3 * (size_t)i + a]); chi[a] = std::max(chi[a], cen[3 * (size_t)i + a]);
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], box[i].lo[a]); b.hi[a] = std::max(b.hi[a], box[i].hi[a]); }
+            for (int a = 0; a < dims; ++a) {
+                clo[a] = std::min(clo[a], cen[(size_t)dims * i + a]); chi[a] = std::max(chi[a], cen[(size_t)dims * i + a]);
             }
         }
         BvhNode node;
@@ -123,29 +150,70 @@ inline BvhBuild build_sphere_bvh(const double *spheres4, uint32_t n)
             node.hi[a] = round_up_f32(b.hi[a] + out.abs_pad);
         }
         const uint32_t cnt = t.end - t.begin;
-        if (cnt <= (uint32_t)kBvhLeafSize) {
-            node.link = (uint32_t)out.prims.size();
-            node.count = cnt;
-            for (uint32_t k = t.begin; k < t.end; ++k) out.prims.push_back(order[k]);
+        if (cnt <= leaf_size) {
+            node.link = (uint32_t)order_out.size();
+            node.count = cnt | leaf_flag;
+            for (uint32_t k = t.begin; k < t.end; ++k) order_out.push_back(order[k]);
             out.nodes.push_back(node);
             continue;
         }
-        // median split of the centroids along their widest axis: balanced, depth <= ceil(log2(n / leaf)) + 1
         int axis = 0;
-        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
-        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        for (int a = 1; a < dims; ++a)
+            if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
         const uint32_t mid = t.begin + cnt / 2;
         std::nth_element(order.begin() + t.begin, order.begin() + mid, order.begin() + t.end,
                          [&](uint32_t x, uint32_t y) {
-                             const double cx = cen[3 * (size_t)x + axis], cy = cen[3 * (size_t)y + axis];
+                             const double cx = cen[(size_t)dims * x + axis], cy = cen[(size_t)dims * y + axis];
                              return cx < cy || (cx == cy && x < y);
                          });
         node.link = 0;            // patched by the right child
         node.count = 0;
         out.nodes.push_back(node);
         // depth-first: the left child must be the next node emitted -> push right first
-        todo.push_back({mid, t.end, (int)me, t.depth + 1});
-        todo.push_back({t.begin, mid, -1, t.depth + 1});
+        todo.push_back({mid, t.end, (int)me});
+        todo.push_back({t.begin, mid, -1});
+    }
+}
+
+// One tree over the sphere boxes (3-D) and the triangle footprints (x, y; z unbounded).  When both kinds are
+// present the root is an interior node whose children are the two sub-trees, so one traversal orders and prunes
+// across both.  Either vector may be empty; a kind with fewer than 5 members gets no sub-tree (has_* = false, the
+// kernel tests those shapes for every segment).  Returns an empty build when the coordinates are too large for
+// the f32 slab test.
+inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::vector<BvhBox> &tri_boxes, uint32_t tri_leaf_size)
+{
+    BvhBuild out;
+    const bool want_s = sphere_boxes.size() > 4, want_t = tri_boxes.size() > 4;
+    if (!want_s && !want_t) return out;
+    double scale = 0.0;
+    auto grow_scale = [&](const std::vector<BvhBox> &v) {
+        for (const BvhBox &b : v)
+            for (int a = 0; a < 3; ++a) {
+                if (std::isfinite(b.lo[a])) scale = std::max(scale, std::fabs(b.lo[a]));
+                if (std::isfinite(b.hi[a])) scale = std::max(scale, std::fabs(b.hi[a]));
+            }
+    };
+    if (want_s) grow_scale(sphere_boxes);
+    if (want_t) grow_scale(tri_boxes);
+    out.origin_limit = 4.0 * scale + 1.0;
+    out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
+    if (!(out.origin_limit < 1.0e30)) return BvhBuild();
+    if (tri_leaf_size < 1) tri_leaf_size = 1;
+    if (tri_leaf_size > (uint32_t)kBvhTriLeafMax) tri_leaf_size = (uint32_t)kBvhTriLeafMax;
+    out.nodes.reserve(2 * (sphere_boxes.size() + tri_boxes.size()) + 4);
+    if (want_s && want_t) out.nodes.emplace_back();                 // joint root, filled in below
+    if (want_s) { bvh_append_tree(sphere_boxes, 3, (uint32_t)kBvhLeafSize, 0u, out, out.prims); out.has_spheres = true; }
+    const uint32_t tri_root = (uint32_t)out.nodes.size();
+    if (want_t) { bvh_append_tree(tri_boxes, 2, tri_leaf_size, kBvhTriLeaf, out, out.tri_order); out.has_tris = true; }
+    if (want_s && want_t) {
+        BvhNode root;
+        for (int a = 0; a < 3; ++a) {
+            root.lo[a] = std::min(out.nodes[1].lo[a], out.nodes[tri_root].lo[a]);
+            root.hi[a] = std::max(out.nodes[1].hi[a], out.nodes[tri_root].hi[a]);
+        }
+        root.link = tri_root;
+        root.count = 0;
+        out.nodes[0] = root;
     }
     return out;
 }
@@ -154,16 +222,17 @@ inline BvhBuild build_sphere_bvh(const double *spheres4, uint32_t n)
 // The traversal is bound by the latency of dependent node fetches, so the binary tree is collapsed into nodes
 // that hold the boxes of up to four children inline: one 128-byte fetch per step, half the depth.
 //   child c: A = {lo.xyz, link}, B = {hi.xyz, count}
-//     count == 0          interior child, link = index of its Bvh4Node
-//     1 <= count <= leaf  leaf child, link = first entry in prims[], count entries
-//     count == 0xFFFFFFFF empty slot (box inverted: never hit)
+//     count == 0               interior child, link = index of its Bvh4Node
+//     1 <= count <= leaf       sphere leaf, link = first entry in prims[] / leaf records, count entries
+//     kBvhTriLeaf | count      triangle leaf, link = first triangle filter record, count records
+//     count == 0xFFFFFFFF      empty slot (box inverted: never hit)
 struct Bvh4Node {
     float4 a[4];
     float4 b[4];
 };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 
-constexpr int kBvh4StackEntries = 24;     // per-ray traversal stack (LDS); deeper trees may overflow it (handled)
+constexpr int kBvh4StackEntries = 30;     // per-ray traversal stack (LDS); deeper trees may overflow it (handled)
 
 struct Bvh4Build {
     std::vector<Bvh4Node> nodes;
@@ -179,6 +248,7 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
     auto area = [&](uint32_t i) {
         const BvhNode &n = b2.nodes[i];
         const double dx = (double)n.hi[0] - n.lo[0], dy = (double)n.hi[1] - n.lo[1], dz = (double)n.hi[2] - n.lo[2];
+        if (!std::isfinite(dz)) return dx + dy;                  // footprint node: what a 2-D ray can hit is its perimeter
         return dx * dy + dy * dz + dz * dx;
     };
     struct Task { uint32_t bin; uint32_t wide; int depth; };

@@ -1,4 +1,4 @@
-// rtx_bvh.hip -- trace_bvh_kernel: closest_object (scene.rs:243-251) over the spheres by flat-BVH traversal.
+// rtx_bvh.hip -- trace_bvh_kernel: closest_object (scene.rs:243-251) by flat-BVH traversal over spheres and triangles.
 //
 // Persistent waves; each lane owns one ray for its whole life (ray state in registers).  A wave takes rays
 // from the global queue 512 at a time (one atomic per 512 rays) and hands them to idle lanes with
@@ -7,17 +7,19 @@
 // children inline), so a step is ONE dependent fetch; children are visited nearest first and boxes whose entry
 // distance exceeds the best hit so far are pruned.
 //
-// Exactness.  The tree only decides WHICH spheres get the exact f64 test of sphere.rs:19-30; it never decides a
-// hit.  (1) Boxes: f32, rounded outward, inflated (rtx_bvh.h); the f32 slab test below widens its interval by the
-// relative rounding error, so it cannot reject a box that contains a reportable intersection.  (2) Leaves: each
-// sphere first passes the conservative f32 discriminant filter of the sweep kernel (rtx_device.h), survivors get
-// the exact test.  (3) Pruning keeps ties (entry <= best), and the winner is the lexicographic minimum of
-// (t, scene index) -- the reference's first-minimal rule.  Planes and triangles are tested exactly and
-// exhaustively (plane.rs is unbounded, triangle.rs has phantom hits: neither can be culled).  Rays whose origin is
-// outside the range the f32 test was validated for sweep all spheres exactly.  Same bits as trace_exact_kernel.
+// Exactness.  The tree only decides WHICH shapes get the exact f64 test (sphere.rs:19-30, triangle.rs:108-127); it
+// never decides a hit.  (1) Boxes: f32, rounded outward, inflated (rtx_bvh.h) -- 3-D for spheres, the (x, y)
+// footprint with unbounded z for triangles, which is what keeps the reference's phantom hits (rtx_bvh.h); the f32
+// slab test widens its interval by the relative rounding error, so it cannot reject a box that contains a
+// reportable hit point.  (2) Leaves: each shape first passes the conservative f32 filter of the sweep kernel
+// (rtx_device.h: sphere discriminant / triangle footprint at q), survivors get the exact test.  (3) Pruning keeps
+// ties (entry <= best), and the winner is the lexicographic minimum of (t, scene index) -- the reference's
+// first-minimal rule.  Planes (unbounded, plane.rs) and shapes the tree does not hold are tested for every segment.
+// Rays whose origin is outside the range the f32 test was validated for, or whose stack overflowed, test every
+// shape exactly.  Same bits as trace_exact_kernel.
 //
-// Bound: latency / L2 bandwidth of the node fetches; algorithmic bytes per segment = box_tests * 32 +
-// leaf_filter_tests * 16 + exact_tests * 32 (BVH config), all counted by the kernel.
+// Bound: VALU issue of the traversal step; algorithmic bytes per segment = box_tests * 32 +
+// leaf_filter_tests * 16|32 + exact_tests * 32|200 (BVH config), all counted by the kernel.
 #include "rtx_launch.h"
 #include "rtx_traverse.h"
 
@@ -38,15 +40,15 @@ __device__ __forceinline__ uint32_t bvh_mbcnt(unsigned long long mask)
 
 }  // namespace
 
+// TRIS: the tree holds triangle leaves.  SPILL: the tree is deep enough that a stack may need more than the LDS
+// entries.  (Both only remove code: the spheres-only shallow-tree variant is what C2 runs.)
+template <bool TRIS, bool SPILL>
 __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kernel(const SceneView *__restrict__ svp,
                                                                    const RowsView *__restrict__ rvp,
                                                                    double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                    unsigned long long *__restrict__ work_counter,
-                                                                   const float4 *__restrict__ nodes,
-                                                                   const float4 *__restrict__ leaf_f32,
-                                                                   const uint32_t *__restrict__ leaf_prims,
-                                                                   const SphereX *__restrict__ spheres,
-                                                                   const uint32_t *__restrict__ sphere_ids)
+                                                                   const float4 *__restrict__ nodes, const LeafArrays la,
+                                                                   uint32_t *__restrict__ spill, uint32_t spill_entries)
 {
     // the hot arrays come in as kernel arguments (= known global address space -> global_load); a pointer read
     // from the SceneView in memory would be `flat`, whose loads also tie up lgkmcnt together with the LDS stack
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
     __shared__ uint32_t lds_q[kBvhQueue][kBvhThreads];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+    const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
     unsigned long long wave_next = 0, wave_end = 0;      // this wave's share of the ray queue (wave-uniform)
@@ -110,12 +113,16 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
             ++segs;
             const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
                                      __builtin_fabsf((float)r.pos.z));
+            bool sweep_spheres = true;                   // shapes the tree did not cover get the exact test below
+            uint32_t tri_sweep_from = 0;
             if (sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit) {          // NaN origin -> exhaustive branch
                 Ray32 q;
                 q.ox = (float)r.pos.x; q.oy = (float)r.pos.y; q.oz = (float)r.pos.z;
                 q.ix = (float)(1.0 / rx.dirn.x); q.iy = (float)(1.0 / rx.dirn.y); q.iz = (float)(1.0 / rx.dirn.z);
                 FilterParams fpar;
-                filter_from_ray(sv, r.pos, r.dir, fpar);
+                TriFilterParams tpar;
+                if (sv.bvh_flags & 1u) filter_from_ray(sv, r.pos, r.dir, fpar); else filter_idle(fpar);
+                if (TRIS && (sv.bvh_flags & 2u)) tri_filter_from_ray(sv, r.pos, r.dir, tpar); else tri_filter_idle(tpar);
                 float best_up = __builtin_inff();
                 uint32_t sp = 0, qcnt = 0, step = 0;
                 bool overflow = false;
@@ -135,26 +142,37 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                     box_tests += 4;
                     // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
                     // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
-                    // sphere) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
+                    // shape) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const uint32_t count = __float_as_uint(cb[c].w);
-                        if (tc[c] < __builtin_inff() && count - 1u < (uint32_t)kBvhLeafSize) {
+                        if (tc[c] < __builtin_inff() && count - 1u < 0x1FFFFu) {          // neither interior (0) nor empty (~0)
                             const uint32_t first = __float_as_uint(ca[c].w);
-                            for (uint32_t k = 0; k < count; ++k) {
-                                const float4 rec = leaf_f32[first + k];
-                                if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
-                                    if (qcnt == (uint32_t)kBvhQueue)
-                                        flush_candidates(spheres, sphere_ids, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
-                                    lds_q[qcnt][tid] = leaf_prims[first + k];
-                                    qcnt += 1;
+                            const uint32_t n = count & 0xFFFFu;
+                            if (TRIS && (count & kBvhTriLeaf)) {
+                                for (uint32_t k = 0; k < n; ++k) {
+                                    const float4 A = la.tri_f32[2 * (size_t)(first + k)], B = la.tri_f32[2 * (size_t)(first + k) + 1];
+                                    if ((int)tri_filter_sign(A, B, tpar) >= 0) {            // q may be above the footprint
+                                        if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                                        lds_q[qcnt][tid] = (first + k) | kQueueTri;
+                                        qcnt += 1;
+                                    }
+                                }
+                            } else {
+                                for (uint32_t k = 0; k < n; ++k) {
+                                    const float4 rec = la.sphere_f32[first + k];
+                                    if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
+                                        if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                                        lds_q[qcnt][tid] = la.sphere_prims[first + k];
+                                        qcnt += 1;
+                                    }
                                 }
                             }
-                            leaf_filters += count;
+                            leaf_filters += n;
                         }
                     }
                     step += 1;
-                    if ((step & 3u) == 0u) flush_candidates(spheres, sphere_ids, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                    if ((step & 3u) == 0u) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                     // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
                     float key[4];
                     uint32_t lnk[4];
@@ -168,29 +186,37 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                     RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
                     // push the farther ones (farthest first), descend into the nearest
-                    // (stack + queue = 32 words of LDS per lane, which is what 16 waves per CU leave; a ray that would
-                    // need more than the 24 stack entries finishes with the exhaustive sweep below)
-                    if (key[3] < __builtin_inff()) { if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = lnk[3]; sp += 1; } else overflow = true; }
-                    if (key[2] < __builtin_inff()) { if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = lnk[2]; sp += 1; } else overflow = true; }
-                    if (key[1] < __builtin_inff()) { if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = lnk[1]; sp += 1; } else overflow = true; }
+                    // (stack + queue = 38 words of LDS per lane, which is what 16 waves per CU leave; entries beyond the 30
+                    // in LDS go to the lane's column of the HBM spill area, which the launcher sizes from the tree's depth
+                    // so that it cannot run out -- the exhaustive sweep below is only a guard)
+#define RTX_PUSH(v)                                                                                      \
+                    {                                                                                                \
+                        if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = (v); sp += 1; }                 \
+                        else if (SPILL && sp - (uint32_t)kBvh4StackEntries < spill_entries) {                        \
+                            spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane] = (v); sp += 1; \
+                        } else overflow = true;                                                                      \
+                    }
+                    if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+                    if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+                    if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
                     node = key[0] < __builtin_inff() ? lnk[0] : kNone;
                     if (node == kNone && sp != 0u) {
-                        sp -= 1;
-                        node = lds_stack[sp][tid];      // its boxes are re-tested against the current bound when it is opened
+                        sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
+                        node = (!SPILL || sp < (uint32_t)kBvh4StackEntries) ? lds_stack[sp][tid]
+                                                                : spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane];
                     }
                 }
-                flush_candidates(spheres, sphere_ids, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
-                if (overflow) {                       // some subtree was dropped: every sphere gets the exact test
-                    for (uint32_t k = 0; k < sv.n_spheres; ++k) {
-                        double t;
-                        if (sphere_distance(sv.spheres[k], rx, &t)) hit_consider(h, t, sv.sphere_id[k], 0, k);
-                    }
-                    exact += sv.n_spheres;
+                flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                if (!overflow) {                      // (a dropped subtree: every shape gets the exact test)
+                    sweep_spheres = (sv.bvh_flags & 1u) == 0u;
+                    tri_sweep_from = (sv.bvh_flags & 2u) ? sv.n_tri_tree : 0u;
                 }
-            } else {
+            }
+            if (sweep_spheres) {
                 for (uint32_t k = 0; k < sv.n_spheres; ++k) {
                     double t;
-                    if (sphere_distance(sv.spheres[k], rx, &t)) hit_consider(h, t, sv.sphere_id[k], 0, k);
+                    if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
                 }
                 exact += sv.n_spheres;
             }
@@ -198,11 +224,13 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                 double t;
                 if (plane_distance(sv.planes[k], rx, &t)) hit_consider(h, t, sv.planes[k].id, 1, k);
             }
-            for (uint32_t k = 0; k < sv.n_tris; ++k) {
+            // triangles outside the tree, by filter record (triangles without a record can never be hit: rtx_api.hip)
+            for (uint32_t k = tri_sweep_from; k < sv.n_tri_filter; ++k) {
+                const uint32_t tk = la.tri_fidx[k];
                 double t;
-                if (triangle_distance(sv.tris[k], rx, &t)) hit_consider(h, t, sv.tris[k].id, 2, k);
+                if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
             }
-            exact += sv.n_planes + sv.n_tris;
+            exact += sv.n_planes + (sv.n_tri_filter - tri_sweep_from);
 
             // ---- render_ray's match arm + ray_hit (scene.rs:232-239, 260-278)
             bool done = true;
@@ -238,17 +266,35 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
     }
 }
 
+// A 4-wide node pushes at most 3 entries per level, so 3 * depth bounds the stack.
+uint32_t bvh_spill_entries(const SceneView &sv)
+{
+    const uint32_t need = 3u * sv.bvh_depth + 2u;
+    return need > (uint32_t)kBvh4StackEntries ? need - (uint32_t)kBvh4StackEntries : 0u;
+}
+
+size_t bvh_spill_bytes(const SceneView &sv, int n_cus)
+{
+    return (size_t)bvh_spill_entries(sv) * (size_t)n_cus * kBvhWavesPerSimd * kBvhThreads * sizeof(uint32_t);
+}
+
 hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
-                            double *samples, Counters *counters, unsigned long long *work_counter, int n_cus,
+                            double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                             hipStream_t stream)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kBvhWavesPerSimd;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(trace_bvh_kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters,
-                       work_counter, reinterpret_cast<const float4 *>(sv.bvh_nodes), sv.bvh_leaf_f32, sv.bvh_prims, sv.spheres,
-                       sv.sphere_id);
+    LeafArrays la;
+    la.sphere_f32 = sv.bvh_leaf_f32; la.sphere_prims = sv.bvh_prims; la.spheres = sv.spheres; la.sphere_ids = sv.sphere_id;
+    la.tri_f32 = sv.tri_f32; la.tri_fidx = sv.tri_fidx; la.tris = sv.tris;
+    const uint32_t spill_entries = spill ? bvh_spill_entries(sv) : 0u;
+    const bool tris = (sv.bvh_flags & 2u) != 0u, deep = spill_entries != 0u;
+    auto kernel = tris ? (deep ? trace_bvh_kernel<true, true> : trace_bvh_kernel<true, false>)
+                       : (deep ? trace_bvh_kernel<false, true> : trace_bvh_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters,
+                       work_counter, reinterpret_cast<const float4 *>(sv.bvh_nodes), la, spill, spill_entries);
     return hipGetLastError();
 }
 

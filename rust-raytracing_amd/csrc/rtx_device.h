@@ -37,14 +37,16 @@ struct SceneView {
                                                // padded to a multiple of 4 spheres
     double          sphere_center[3];          // centre of the bounding box of sphere centres and triangle vertices
     double          sphere_cmax;               // max over spheres of |c - centre| + r
-    // flat BVH over the spheres (rtx_bvh.h); null when the scene has none
+    // flat BVH over the sphere boxes and triangle footprints (rtx_bvh.h); null when the scene has none
     const Bvh4Node *bvh_nodes;                 // 4-wide nodes, 128 B each; node 0 is the root
     const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
-    const float4   *bvh_leaf_f32;              // per leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
+    const float4   *bvh_leaf_f32;              // per sphere leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
     uint32_t        n_bvh_nodes;
     uint32_t        bvh_depth;
     float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
-    float           pad_;
+    uint32_t        bvh_flags;                 // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
+    uint32_t        n_tri_tree;                // triangle filter records [0, n_tri_tree) are in leaf order (a triangle leaf's link
+    uint32_t        pad1_;                     // indexes them); [n_tri_tree, n_tri_filter) are outside the tree
 };
 
 // Which pixels/samples one launch covers.

@@ -19,18 +19,13 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
                               double *samples, double *state, Counters *counters, unsigned long long *work_counter,
                               int n_cus, bool verify, hipStream_t stream);
 
-// BVH kernel: persistent waves, one ray per lane, per-lane stack traversal of the flat sphere BVH with an f64
-// slab test; leaves and the other shapes use the exact f64 tests.  work_counter: zeroed u64 ray-queue head.
+// BVH kernel: persistent waves, one ray per lane, per-lane stack traversal of the flat BVH (sphere boxes, triangle
+// footprints) with a conservative f32 slab test; leaves and the shapes outside the tree use the exact f64 tests.  work_counter: zeroed u64 ray-queue head.
+// spill: bvh_spill_bytes(sv, n_cus) bytes of device scratch for stack entries beyond the LDS stack (may be null when 0).
+size_t bvh_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
-                            double *samples, Counters *counters, unsigned long long *work_counter, int n_cus,
+                            double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                             hipStream_t stream);
-
-// POOL kernel: the BVH traversal with a wave-local pool of 256 rays (state in HBM SoA, pool_state_bytes(n_cus) bytes)
-// from which lanes pull the next ray as soon as their traversal ends.
-size_t pool_state_bytes(int n_cus);
-hipError_t launch_trace_pool(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
-                             double *samples, char *pool_mem, Counters *counters, unsigned long long *work_counter, int n_cus,
-                             hipStream_t stream);
 
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
 // sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.

@@ -38,18 +38,34 @@ __device__ __forceinline__ float round_up32(double best)
     return b;
 }
 
-constexpr int kBvhQueue = 8;                // candidate spheres a lane may hold between two exact passes
+constexpr int kBvhQueue = 8;                // candidate shapes a lane may hold between two exact passes
+constexpr uint32_t kQueueTri = 0x80000000u; // queue entry: a triangle filter record (else a local sphere index)
 
-// Exact f64 tests (sphere.rs:19-30) of the queued candidates; updates the winner and the pruning bound.
-__device__ __forceinline__ void flush_candidates(const SphereX *__restrict__ spheres, const uint32_t *__restrict__ sphere_ids,
-                                                 const RayX &rx, const uint32_t *lds_q, uint32_t tid, uint32_t &qcnt, Hit &h,
-                                                 float &best_up, unsigned long long &exact)
+struct LeafArrays {                         // the arrays the leaves index (kernel arguments: global address space)
+    const float4 *sphere_f32;               // per sphere leaf entry
+    const uint32_t *sphere_prims;
+    const SphereX *spheres;
+    const uint32_t *sphere_ids;
+    const float4 *tri_f32;                  // two per triangle filter record
+    const uint32_t *tri_fidx;
+    const TriX *tris;
+};
+
+// Exact f64 tests (sphere.rs:19-30, triangle.rs:108-127) of the queued candidates; updates the winner and the
+// pruning bound.
+__device__ __forceinline__ void flush_candidates(const LeafArrays &la, const RayX &rx, const uint32_t *lds_q, uint32_t tid,
+                                                 uint32_t &qcnt, Hit &h, float &best_up, unsigned long long &exact)
 {
 #pragma unroll 1
-    for (uint32_t k = 0; k < qcnt; ++k) {         // not unrolled: 8 inlined copies of the f64 test per call site bloat the traversal loop
+    for (uint32_t k = 0; k < qcnt; ++k) {         // not unrolled: 8 inlined copies of the f64 tests per call site bloat the traversal loop
         const uint32_t idx = lds_q[(size_t)k * kBvhThreads + tid];
         double t;
-        if (sphere_distance(spheres[idx], rx, &t)) hit_consider(h, t, sphere_ids[idx], 0, idx);
+        if (idx & kQueueTri) {
+            const uint32_t tk = la.tri_fidx[idx & ~kQueueTri];
+            if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+        } else {
+            if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
+        }
     }
     exact += qcnt;
     qcnt = 0;

@@ -32,7 +32,7 @@ def gpu(rtx):
 
 
 def _kernels(rtx):
-    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_POOL]
+    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH]
 
 
 # ---- device arithmetic ---------------------------------------------------------------------------
@@ -73,7 +73,7 @@ def test_hip_matches_oracle_seeded(gpu, oracle, case):
         "tris": (scenes.light_every(scenes.compact(scenes.random_triangles(400, 5)), 3), 48, 32, dict(rays_per_pixel=3, seed=8)),
     }[case]
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_POOL):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
         scene = hip_scene(gpu, objs, kernel=kern, **cfg)
         img = scene.render(w, h)
         assert max_abs_diff(img, ref) <= ATOL, (case, kern)
@@ -161,7 +161,7 @@ def test_triangle_filter_classes_and_no_mismatch(gpu, oracle):
     w, h = 72, 48
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
     assert ref.mean() > 0.01
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
         assert max_abs_diff(hip_render(gpu, objs, w, h, kernel=kern, **cfg), ref) <= ATOL
     hnd = hip_scene(gpu, objs, kernel=gpu.RTX_KERNEL_MIXED_VERIFY, **cfg).upload(0)
     buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
@@ -171,6 +171,44 @@ def test_triangle_filter_classes_and_no_mismatch(gpu, oracle):
     assert max_abs_diff(buf.cpu().numpy(), ref) <= ATOL
     # the filter did real work: far fewer exact tests than segments x triangles
     assert st.exact_tests < 0.2 * st.segments * len(objs)
+
+
+@pytest.mark.parametrize("n_tris,w,h,spp", [(100000, 240, 135, 2), (600000, 96, 54, 1)])
+def test_bvh_triangle_footprint_tree_is_bit_identical_to_exact_kernel(gpu, n_tris, w, h, spp):
+    """Triangles are in the BVH with their (x, y) footprint and unbounded z (rtx_bvh.h): the reference's phantom hits
+    (|t| of the plane distance, 2-row containment) survive the culling.  C3-recipe meshes at sizes the oracle would
+    need minutes for, against the exhaustive f64 kernel: same bits, same segment count, ~1e4 x fewer exact tests.
+    The 600k mesh is deep enough for the traversal stack to spill from LDS to HBM (SPILL variant)."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.random_triangles(n_tris, 2)
+    cam = gpu.Camera(*scenes.CAMERA)
+    out = {}
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
+        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, kernel=kern), cam, objs).upload(0)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        out[kern] = (buf.cpu().numpy(), st.segments, st.exact_tests, st.kernel)
+        hnd.close()
+    a, b, c = out[gpu.RTX_KERNEL_EXACT], out[gpu.RTX_KERNEL_BVH], out[gpu.RTX_KERNEL_AUTO]
+    assert a[0].mean() > 0.01 and np.isfinite(a[0]).all()
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert b[2] < a[2] / 1000
+    assert c[3] == gpu.RTX_KERNEL_BVH and np.array_equal(a[0], c[0])       # AUTO picks the tree for triangle meshes
+
+
+def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
+    """Spheres + triangles + a plane under one root; camera variants: inside the cloud looking along -z (rays nearly
+    parallel to the footprints' unbounded axis), exactly axis-parallel directions (0 * inf in the slab test), and far
+    outside the tree's validated origin range (those rays test every shape exactly)."""
+    from rust_raytracing_amd import scenes
+    objs = scenes.mixed_scene(80, 120, 1, seed=33)
+    cfg = dict(rays_per_pixel=2, seed=5)
+    for cam in (((8.0, 0.5, 6.0), (0.0, 0.0, -1.0), 1.2), ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), 1e-9),
+                ((8.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1e-9), ((-5000.0, 30.0, 10.0), (1.0, 0.0, 0.0), 0.02)):
+        ref = oracle_render(oracle, objs, 40, 24, cam=cam, **cfg)
+        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_MIXED):
+            assert max_abs_diff(hip_render(gpu, objs, 40, 24, cam=cam, kernel=kern, **cfg), ref) <= ATOL, (cam, kern)
 
 
 def test_many_identical_spheres_first_wins(gpu, oracle):
@@ -356,7 +394,7 @@ def test_edge_scenes_match_oracle(gpu, oracle, name):
     objs, cam, cfg = _edge_scene(name)
     w, h = 40, 28
     ref, seg = oracle_render(oracle, objs, w, h, cam=cam, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_POOL, gpu.RTX_KERNEL_AUTO):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
         img = hip_render(gpu, objs, w, h, cam=cam, kernel=kern, **cfg)
         assert np.array_equal(np.isnan(img), np.isnan(ref)), (name, kern)
         scale = max(1.0, float(np.nanmax(np.abs(ref))) if np.isfinite(np.nanmax(np.abs(ref))) else 1.0)

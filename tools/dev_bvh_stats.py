@@ -5,7 +5,7 @@ import rust_raytracing_amd as rtx
 from rust_raytracing_amd import scenes
 objs = scenes.random_spheres(10000, 1)
 w, h, spp = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 8
-for kern in (rtx.RTX_KERNEL_POOL, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_MIXED):
+for kern in (rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_MIXED):
     hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, kernel=kern), rtx.Camera(*scenes.CAMERA), objs).upload(0)
     buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
     for it in range(2):
