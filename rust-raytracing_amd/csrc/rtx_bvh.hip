@@ -40,6 +40,92 @@ __device__ __forceinline__ uint32_t bvh_mbcnt(unsigned long long mask)
 
 }  // namespace
 
+// One traversal step of one lane: open wide node `node`, filter its leaf children into the candidate queue, push
+// the interior children still in reach (farthest first) and move to the nearest (or pop).  node == kNone afterwards
+// means the traversal is complete.
+template <bool TRIS, bool SPILL>
+__device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const LeafArrays &la, const Ray32 &q,
+                                         const FilterParams &fpar, const TriFilterParams &tpar, const RayX &rx, uint32_t &node,
+                                         uint32_t &sp, uint32_t &qcnt, bool &overflow, Hit &h, float &best_up,
+                                         uint32_t *lds_stack, uint32_t *lds_q, uint32_t tid, uint32_t *__restrict__ spill,
+                                         uint32_t spill_entries, size_t spill_stride, size_t glane,
+                                         unsigned long long &box_tests, unsigned long long &leaf_filters, unsigned long long &exact)
+{
+    // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
+    const float4 *np = nodes + 8 * (size_t)node;
+    float4 ca[4], cb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+    float tc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+    box_tests += 4;
+    // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
+    // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
+    // shape) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t count = __float_as_uint(cb[c].w);
+        if (tc[c] < __builtin_inff() && count - 1u < 0x1FFFFu) {          // neither interior (0) nor empty (~0)
+            const uint32_t first = __float_as_uint(ca[c].w);
+            const uint32_t n = count & 0xFFFFu;
+            if (TRIS && (count & kBvhTriLeaf)) {
+                for (uint32_t k = 0; k < n; ++k) {
+                    const float4 A = la.tri_f32[2 * (size_t)(first + k)], B = la.tri_f32[2 * (size_t)(first + k) + 1];
+                    if ((int)tri_filter_sign(A, B, tpar) >= 0) {            // q may be above the footprint
+                        if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+                        lds_q[(size_t)qcnt * kBvhThreads + tid] = (first + k) | kQueueTri;
+                        qcnt += 1;
+                    }
+                }
+            } else {
+                for (uint32_t k = 0; k < n; ++k) {
+                    const float4 rec = la.sphere_f32[first + k];
+                    if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
+                        if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+                        lds_q[(size_t)qcnt * kBvhThreads + tid] = la.sphere_prims[first + k];
+                        qcnt += 1;
+                    }
+                }
+            }
+            leaf_filters += n;
+        }
+    }
+    // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
+    float key[4];
+    uint32_t lnk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool go = __float_as_uint(cb[c].w) == 0u && tc[c] < __builtin_inff() && tc[c] <= best_up;
+        key[c] = go ? tc[c] : __builtin_inff();
+        lnk[c] = __float_as_uint(ca[c].w);
+    }
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    // push the farther ones (farthest first), descend into the nearest
+    // (stack + queue = 38 words of LDS per lane, which is what 16 waves per CU leave; entries beyond the 30
+    // in LDS go to the lane's column of the HBM spill area, which the launcher sizes from the tree's depth
+    // so that it cannot run out -- the exhaustive sweep below is only a guard)
+#define RTX_PUSH(v)                                                                                      \
+    {                                                                                                \
+        if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; }                 \
+        else if (SPILL && sp - (uint32_t)kBvh4StackEntries < spill_entries) {                        \
+            spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane] = (v); sp += 1; \
+        } else overflow = true;                                                                      \
+    }
+    if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+    if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+    if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
+    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
+        node = (!SPILL || sp < (uint32_t)kBvh4StackEntries) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane];
+    }
+}
+
 // TRIS: the tree holds triangle leaves.  SPILL: the tree is deep enough that a stack may need more than the LDS
 // entries.  (Both only remove code: the spheres-only shallow-tree variant is what C2 runs.)
 template <bool TRIS, bool SPILL>
@@ -69,6 +155,10 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
 #ifdef RTX_BVH_STATS
     unsigned long long wave_steps = 0;      // diagnostic: traversal-loop iterations of the wave (reported via exact_tests)
+    unsigned long long cyc_trav = 0, cyc_other = 0, cyc_mark = __builtin_amdgcn_s_memtime();   // (reported via filter_tests / box_tests)
+#define RTX_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - cyc_mark; cyc_mark = now_; }
+#else
+#define RTX_MARK(acc)
 #endif
 
     for (;;) {
@@ -127,86 +217,17 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                 uint32_t sp = 0, qcnt = 0, step = 0;
                 bool overflow = false;
                 uint32_t node = 0;                       // wide node 0 is the root
+                RTX_MARK(cyc_other)
                 while (node != kNone) {
 #ifdef RTX_BVH_STATS
                     { const unsigned long long am = __ballot(true); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) wave_steps += 1; }
 #endif
-                    // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
-                    const float4 *np = nodes + 8 * (size_t)node;
-                    float4 ca[4], cb[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
-                    float tc[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) tc[c] = box_entry32(ca[c], cb[c], q, best_up);
-                    box_tests += 4;
-                    // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
-                    // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
-                    // shape) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t count = __float_as_uint(cb[c].w);
-                        if (tc[c] < __builtin_inff() && count - 1u < 0x1FFFFu) {          // neither interior (0) nor empty (~0)
-                            const uint32_t first = __float_as_uint(ca[c].w);
-                            const uint32_t n = count & 0xFFFFu;
-                            if (TRIS && (count & kBvhTriLeaf)) {
-                                for (uint32_t k = 0; k < n; ++k) {
-                                    const float4 A = la.tri_f32[2 * (size_t)(first + k)], B = la.tri_f32[2 * (size_t)(first + k) + 1];
-                                    if ((int)tri_filter_sign(A, B, tpar) >= 0) {            // q may be above the footprint
-                                        if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
-                                        lds_q[qcnt][tid] = (first + k) | kQueueTri;
-                                        qcnt += 1;
-                                    }
-                                }
-                            } else {
-                                for (uint32_t k = 0; k < n; ++k) {
-                                    const float4 rec = la.sphere_f32[first + k];
-                                    if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {   // D >= 0: cannot be excluded
-                                        if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
-                                        lds_q[qcnt][tid] = la.sphere_prims[first + k];
-                                        qcnt += 1;
-                                    }
-                                }
-                            }
-                            leaf_filters += n;
-                        }
-                    }
+                    bvh_step<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, node, sp, qcnt, overflow, h, best_up, &lds_stack[0][0], &lds_q[0][0],
+                                          tid, spill, spill_entries, spill_stride, glane, box_tests, leaf_filters, exact);
                     step += 1;
                     if ((step & 3u) == 0u) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
-                    // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
-                    float key[4];
-                    uint32_t lnk[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const bool go = __float_as_uint(cb[c].w) == 0u && tc[c] < __builtin_inff() && tc[c] <= best_up;
-                        key[c] = go ? tc[c] : __builtin_inff();
-                        lnk[c] = __float_as_uint(ca[c].w);
-                    }
-#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
-                    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
-#undef RTX_CSWAP
-                    // push the farther ones (farthest first), descend into the nearest
-                    // (stack + queue = 38 words of LDS per lane, which is what 16 waves per CU leave; entries beyond the 30
-                    // in LDS go to the lane's column of the HBM spill area, which the launcher sizes from the tree's depth
-                    // so that it cannot run out -- the exhaustive sweep below is only a guard)
-#define RTX_PUSH(v)                                                                                      \
-                    {                                                                                                \
-                        if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[sp][tid] = (v); sp += 1; }                 \
-                        else if (SPILL && sp - (uint32_t)kBvh4StackEntries < spill_entries) {                        \
-                            spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane] = (v); sp += 1; \
-                        } else overflow = true;                                                                      \
-                    }
-                    if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
-                    if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
-                    if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
-#undef RTX_PUSH
-                    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
-                    if (node == kNone && sp != 0u) {
-                        sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
-                        node = (!SPILL || sp < (uint32_t)kBvh4StackEntries) ? lds_stack[sp][tid]
-                                                                : spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane];
-                    }
                 }
+                RTX_MARK(cyc_trav)
                 flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                 if (!overflow) {                      // (a dropped subtree: every shape gets the exact test)
                     sweep_spheres = (sv.bvh_flags & 1u) == 0u;
@@ -246,10 +267,14 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
         }
     }
     // counters: segments, exact f64 shape tests, box tests + leaf filter tests (reported through filter_tests)
-#ifdef RTX_BVH_STATS
-    exact = wave_steps;
-#endif
     unsigned long long filt = box_tests + leaf_filters;
+#ifdef RTX_BVH_STATS
+    RTX_MARK(cyc_other)
+    exact = wave_steps;
+    filt = lane == 0 ? cyc_trav : 0ull;
+    box_tests = lane == 0 ? cyc_other : 0ull;
+#endif
+#undef RTX_MARK
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         segs += __shfl_xor(segs, off, 64);
@@ -293,8 +318,8 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
     const bool tris = (sv.bvh_flags & 2u) != 0u, deep = spill_entries != 0u;
     auto kernel = tris ? (deep ? trace_bvh_kernel<true, true> : trace_bvh_kernel<true, false>)
                        : (deep ? trace_bvh_kernel<false, true> : trace_bvh_kernel<false, false>);
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters,
-                       work_counter, reinterpret_cast<const float4 *>(sv.bvh_nodes), la, spill, spill_entries);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
+                       reinterpret_cast<const float4 *>(sv.bvh_nodes), la, spill, spill_entries);
     return hipGetLastError();
 }
 
