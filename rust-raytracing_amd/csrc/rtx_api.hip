@@ -324,7 +324,8 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     for (size_t k = 0; k < spheres.size() && spheres_finite; ++k)
         spheres_finite = sphere_box(scene->objects[sphere_id[k]].geom, sphere_boxes[k]);
     if (!spheres_finite) sphere_boxes.clear();
-    BvhBuild bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size());
+    static const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
+    BvhBuild bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(), use_sah);
     Bvh4Build bvh4 = collapse_to_bvh4(bvh);
 
     // records in leaf order first (a triangle leaf's link indexes them), then the always-candidates
@@ -354,7 +355,11 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     h->sv.n_bvh_nodes = (uint32_t)bvh4.nodes.size();
     h->sv.bvh_depth = (uint32_t)bvh4.depth;
     h->sv.bvh_origin_limit = (float)bvh.origin_limit;
+    h->sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
     h->sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);
+    if (std::getenv("RTX_HIP_DEBUG"))
+        std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree, %zu always tested), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
+                     spheres.size(), tris.size(), plain_recs.size(), always_recs.size(), bvh.nodes.size(), bvh4.nodes.size(), bvh4.depth);
     std::vector<float4> leaf32(bvh.prims.size());
     for (size_t k = 0; k < bvh.prims.size(); ++k) {
         const uint32_t p = bvh.prims[k];

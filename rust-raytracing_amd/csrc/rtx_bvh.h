@@ -62,8 +62,9 @@ struct BvhBuild {
     std::vector<uint32_t> prims;          // local sphere indices, leaf-contiguous
     std::vector<uint32_t> tri_order;      // triangle (footprint) indices, leaf-contiguous
     bool has_spheres = false, has_tris = false;
-    // The traversal's slab test runs in f32: t = fl(fl(b - fl(o)) * fl(1/d)).  Rounding the origin shifts both faces
-    // of an axis by at most 2^-24 |o|, every other rounding is a relative error <= 2^-22 on t (handled in the test).
+    // The traversal's slab test runs in f32: t = fl(b * inv + noi), inv = fl(1/d), noi = fl(-o * inv) (rtx_traverse.h).
+    // Rounding noi shifts both faces of an axis by at most 2^-24 |o|, the other roundings are a relative error
+    // <= 2^-22 on t (handled in the test).
     // Every box is therefore also inflated by `abs_pad` >= 2^-22 * origin_limit on each side; rays whose origin lies
     // outside |o|_inf <= origin_limit do not use the tree (they sweep the shapes exhaustively).
     double origin_limit = 0.0;
@@ -115,10 +116,16 @@ inline bool triangle_footprint(const double v[9], BvhBox &b)
 }
 
 // Appends the binary tree over `box` to out.nodes (its root is the first node appended) and the leaf order to
-// `order`.  Median split of the box centres along the widest of the first `dims` axes: balanced, depth <=
-// ceil(log2(n / leaf)) + 1.
+// `order`.  Splits: binned surface-area heuristic over the box centres (16 bins per axis, the first `dims` axes;
+// the "area" of a footprint node is its perimeter, which is what a 2-D ray can hit), i.e. the split that minimises
+// area(L) * n(L) + area(R) * n(R).  When the SAH has nothing to offer (all centres in one bin) or the depth budget
+// is used up, the node is split at the median of its widest axis, which bounds the depth by
+// ceil(log2(n / leaf)) + kBvhSahExtraDepth + 1.
+constexpr int kBvhSahBins = 16;
+constexpr int kBvhSahExtraDepth = 6;
+
 inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t leaf_size, uint32_t leaf_flag,
-                            BvhBuild &out, std::vector<uint32_t> &order_out)
+                            BvhBuild &out, std::vector<uint32_t> &order_out, bool use_sah = true)
 {
     const uint32_t n = (uint32_t)box.size();
     std::vector<double> cen((size_t)dims * n);
@@ -126,20 +133,37 @@ inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t l
         for (int a = 0; a < dims; ++a) cen[(size_t)dims * i + a] = 0.5 * (box[i].lo[a] + box[i].hi[a]);
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
-    struct Task { uint32_t begin, end; int parent; };     // parent < 0: nothing to patch; else parent's link is set when this (right) child is emitted
+    int balanced_depth = 1;
+    for (uint64_t c = leaf_size; c < n; c *= 2) ++balanced_depth;
+    const int max_depth = balanced_depth + kBvhSahExtraDepth;
+    auto measure = [dims](const BvhBox &b) {
+        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1];
+        if (dims == 2) return dx + dy;
+        const double dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto grow = [](BvhBox &b, const BvhBox &o) {
+        for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], o.lo[a]); b.hi[a] = std::max(b.hi[a], o.hi[a]); }
+    };
+    auto empty_box = [] {
+        BvhBox b;
+        for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+        return b;
+    };
+    struct Task { uint32_t begin, end; int parent; int depth; };     // parent < 0: nothing to patch; else parent's link is set when this (right) child is emitted
     std::vector<Task> todo;
-    todo.push_back({0u, n, -1});
+    todo.push_back({0u, n, -1, 1});
     while (!todo.empty()) {
         const Task t = todo.back();
         todo.pop_back();
         const uint32_t me = (uint32_t)out.nodes.size();
         if (t.parent >= 0) out.nodes[(size_t)t.parent].link = me;   // we are a RIGHT child (left children are emitted right after their parent)
-        BvhBox b;
+        BvhBox b = empty_box();
         double clo[3], chi[3];
-        for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; clo[a] = INFINITY; chi[a] = -INFINITY; }
+        for (int a = 0; a < 3; ++a) { clo[a] = INFINITY; chi[a] = -INFINITY; }
         for (uint32_t k = t.begin; k < t.end; ++k) {
             const uint32_t i = order[k];
-            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], box[i].lo[a]); b.hi[a] = std::max(b.hi[a], box[i].hi[a]); }
+            grow(b, box[i]);
             for (int a = 0; a < dims; ++a) {
                 clo[a] = std::min(clo[a], cen[(size_t)dims * i + a]); chi[a] = std::max(chi[a], cen[(size_t)dims * i + a]);
             }
@@ -157,21 +181,80 @@ inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t l
             out.nodes.push_back(node);
             continue;
         }
-        int axis = 0;
-        for (int a = 1; a < dims; ++a)
-            if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-        const uint32_t mid = t.begin + cnt / 2;
-        std::nth_element(order.begin() + t.begin, order.begin() + mid, order.begin() + t.end,
-                         [&](uint32_t x, uint32_t y) {
-                             const double cx = cen[(size_t)dims * x + axis], cy = cen[(size_t)dims * y + axis];
-                             return cx < cy || (cx == cy && x < y);
-                         });
+        uint32_t mid = 0;
+        // the depth budget left must still allow a balanced finish: 2^(max_depth - depth) * leaf >= cnt
+        bool sah_allowed = use_sah && cnt > 2;
+        if (sah_allowed) {
+            int need = 1;
+            for (uint64_t c = leaf_size; c < cnt; c *= 2) ++need;
+            sah_allowed = t.depth + need < max_depth;       // one level of slack for the uneven split
+        }
+        if (sah_allowed) {
+            double best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < dims; ++a) {
+                const double ext = chi[a] - clo[a];
+                if (!(ext > 0.0)) continue;
+                BvhBox bin_box[kBvhSahBins];
+                uint32_t bin_cnt[kBvhSahBins];
+                for (int k = 0; k < kBvhSahBins; ++k) { bin_box[k] = empty_box(); bin_cnt[k] = 0; }
+                const double scale = (double)kBvhSahBins / ext;
+                for (uint32_t k = t.begin; k < t.end; ++k) {
+                    const uint32_t i = order[k];
+                    int bi = (int)((cen[(size_t)dims * i + a] - clo[a]) * scale);
+                    bi = bi < 0 ? 0 : (bi >= kBvhSahBins ? kBvhSahBins - 1 : bi);
+                    grow(bin_box[bi], box[i]);
+                    bin_cnt[bi] += 1;
+                }
+                double right_m[kBvhSahBins];
+                uint32_t right_n[kBvhSahBins];
+                BvhBox acc = empty_box();
+                uint32_t accn = 0;
+                for (int k = kBvhSahBins - 1; k >= 1; --k) {
+                    if (bin_cnt[k]) grow(acc, bin_box[k]);
+                    accn += bin_cnt[k];
+                    right_m[k] = accn ? measure(acc) : 0.0;
+                    right_n[k] = accn;
+                }
+                acc = empty_box();
+                accn = 0;
+                for (int k = 0; k + 1 < kBvhSahBins; ++k) {           // split after bin k
+                    if (bin_cnt[k]) grow(acc, bin_box[k]);
+                    accn += bin_cnt[k];
+                    if (accn == 0 || right_n[k + 1] == 0) continue;
+                    const double cost = measure(acc) * accn + right_m[k + 1] * right_n[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                const double ext = chi[best_axis] - clo[best_axis];
+                const double scale = (double)kBvhSahBins / ext;
+                auto in_left = [&](uint32_t i) {
+                    int bi = (int)((cen[(size_t)dims * i + best_axis] - clo[best_axis]) * scale);
+                    bi = bi < 0 ? 0 : (bi >= kBvhSahBins ? kBvhSahBins - 1 : bi);
+                    return bi <= best_bin;
+                };
+                mid = (uint32_t)(std::stable_partition(order.begin() + t.begin, order.begin() + t.end, in_left) - order.begin());
+            }
+        }
+        if (mid <= t.begin || mid >= t.end) {
+            // median split of the centres along their widest axis
+            int axis = 0;
+            for (int a = 1; a < dims; ++a)
+                if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+            mid = t.begin + cnt / 2;
+            std::nth_element(order.begin() + t.begin, order.begin() + mid, order.begin() + t.end,
+                             [&](uint32_t x, uint32_t y) {
+                                 const double cx = cen[(size_t)dims * x + axis], cy = cen[(size_t)dims * y + axis];
+                                 return cx < cy || (cx == cy && x < y);
+                             });
+        }
         node.link = 0;            // patched by the right child
         node.count = 0;
         out.nodes.push_back(node);
         // depth-first: the left child must be the next node emitted -> push right first
-        todo.push_back({mid, t.end, (int)me});
-        todo.push_back({t.begin, mid, -1});
+        todo.push_back({mid, t.end, (int)me, t.depth + 1});
+        todo.push_back({t.begin, mid, -1, t.depth + 1});
     }
 }
 
@@ -180,7 +263,8 @@ inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t l
 // across both.  Either vector may be empty; a kind with fewer than 5 members gets no sub-tree (has_* = false, the
 // kernel tests those shapes for every segment).  Returns an empty build when the coordinates are too large for
 // the f32 slab test.
-inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::vector<BvhBox> &tri_boxes, uint32_t tri_leaf_size)
+inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::vector<BvhBox> &tri_boxes, uint32_t tri_leaf_size,
+                          bool use_sah = true)
 {
     BvhBuild out;
     const bool want_s = sphere_boxes.size() > 4, want_t = tri_boxes.size() > 4;
@@ -197,14 +281,14 @@ inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::ve
     if (want_t) grow_scale(tri_boxes);
     out.origin_limit = 4.0 * scale + 1.0;
     out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
-    if (!(out.origin_limit < 1.0e30)) return BvhBuild();
+    if (!(out.origin_limit < 1.0e28)) return BvhBuild();
     if (tri_leaf_size < 1) tri_leaf_size = 1;
     if (tri_leaf_size > (uint32_t)kBvhTriLeafMax) tri_leaf_size = (uint32_t)kBvhTriLeafMax;
     out.nodes.reserve(2 * (sphere_boxes.size() + tri_boxes.size()) + 4);
     if (want_s && want_t) out.nodes.emplace_back();                 // joint root, filled in below
-    if (want_s) { bvh_append_tree(sphere_boxes, 3, (uint32_t)kBvhLeafSize, 0u, out, out.prims); out.has_spheres = true; }
+    if (want_s) { bvh_append_tree(sphere_boxes, 3, (uint32_t)kBvhLeafSize, 0u, out, out.prims, use_sah); out.has_spheres = true; }
     const uint32_t tri_root = (uint32_t)out.nodes.size();
-    if (want_t) { bvh_append_tree(tri_boxes, 2, tri_leaf_size, kBvhTriLeaf, out, out.tri_order); out.has_tris = true; }
+    if (want_t) { bvh_append_tree(tri_boxes, 2, tri_leaf_size, kBvhTriLeaf, out, out.tri_order, use_sah); out.has_tris = true; }
     if (want_s && want_t) {
         BvhNode root;
         for (int a = 0; a < 3; ++a) {
@@ -225,7 +309,7 @@ inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::ve
 //     count == 0               interior child, link = index of its Bvh4Node
 //     1 <= count <= leaf       sphere leaf, link = first entry in prims[] / leaf records, count entries
 //     kBvhTriLeaf | count      triangle leaf, link = first triangle filter record, count records
-//     count == 0xFFFFFFFF      empty slot (box inverted: never hit)
+//     count == 0xFFFFFFFF      empty slot (neither leaf nor interior: ignored whatever its box test says)
 struct Bvh4Node {
     float4 a[4];
     float4 b[4];

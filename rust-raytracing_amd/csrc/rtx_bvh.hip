@@ -207,8 +207,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
             uint32_t tri_sweep_from = 0;
             if (sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit) {          // NaN origin -> exhaustive branch
                 Ray32 q;
-                q.ox = (float)r.pos.x; q.oy = (float)r.pos.y; q.oz = (float)r.pos.z;
-                q.ix = (float)(1.0 / rx.dirn.x); q.iy = (float)(1.0 / rx.dirn.y); q.iz = (float)(1.0 / rx.dirn.z);
+                make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
                 FilterParams fpar;
                 TriFilterParams tpar;
                 if (sv.bvh_flags & 1u) filter_from_ray(sv, r.pos, r.dir, fpar); else filter_idle(fpar);

@@ -46,7 +46,7 @@ struct SceneView {
     float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
     uint32_t        bvh_flags;                 // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
     uint32_t        n_tri_tree;                // triangle filter records [0, n_tri_tree) are in leaf order (a triangle leaf's link
-    uint32_t        pad1_;                     // indexes them); [n_tri_tree, n_tri_filter) are outside the tree
+    float           bvh_inv_max;               // indexes them); [n_tri_tree, n_tri_filter) are outside the tree.  bvh_inv_max: rtx_traverse.h
 };
 
 // Which pixels/samples one launch covers.
