@@ -88,7 +88,7 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
                 if (cand) entry = la.sphere_prims[first + k];
             }
             if (cand) {
-                if (qcnt == (uint32_t)kBvhQueue) flush_candidates(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+                if (qcnt == (uint32_t)kBvhQueue) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
                 lds_q[(size_t)qcnt * kBvhThreads + tid] = entry;
                 qcnt += 1;
             }
@@ -100,8 +100,7 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
     uint32_t lnk[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const bool go = __float_as_uint(cb[c].w) == 0u && tc[c] < __builtin_inff() && tc[c] <= best_up;
-        key[c] = go ? tc[c] : __builtin_inff();
+        key[c] = __float_as_uint(cb[c].w) == 0u ? tc[c] : __builtin_inff();     // (tc is already inf for a box out of reach)
         lnk[c] = __float_as_uint(ca[c].w);
     }
 #define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
@@ -240,12 +239,12 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                     bvh_step<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, node, sp, qcnt, overflow, h, best_up, &lds_stack[0][0], &lds_q[0][0],
                                           tid, spill, spill_entries, spill_stride, glane, nbox, nleaf, exact);
                     step += 1;
-                    if ((step & 3u) == 0u) flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                    if ((step & 3u) == 0u) flush_candidates<TRIS>(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                 }
                 RTX_MARK(cyc_trav)
                 box_tests += nbox;
                 leaf_filters += nleaf;
-                flush_candidates(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                flush_candidates<TRIS>(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                 if (!overflow) {                      // (a dropped subtree: every shape gets the exact test)
                     sweep_spheres = (sv.bvh_flags & 1u) == 0u;
                     tri_sweep_from = (sv.bvh_flags & 2u) ? sv.n_tri_tree : 0u;

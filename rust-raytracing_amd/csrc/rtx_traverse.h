@@ -73,6 +73,7 @@ struct LeafArrays {                         // the arrays the leaves index (kern
 
 // Exact f64 tests (sphere.rs:19-30, triangle.rs:108-127) of the queued candidates; updates the winner and the
 // pruning bound.
+template <bool TRIS>
 __device__ __forceinline__ void flush_candidates(const LeafArrays &la, const RayX &rx, const uint32_t *lds_q, uint32_t tid,
                                                  uint32_t &qcnt, Hit &h, float &best_up, unsigned long long &exact)
 {
@@ -80,7 +81,7 @@ __device__ __forceinline__ void flush_candidates(const LeafArrays &la, const Ray
     for (uint32_t k = 0; k < qcnt; ++k) {         // not unrolled: 8 inlined copies of the f64 tests per call site bloat the traversal loop
         const uint32_t idx = lds_q[(size_t)k * kBvhThreads + tid];
         double t;
-        if (idx & kQueueTri) {
+        if (TRIS && (idx & kQueueTri)) {
             const uint32_t tk = la.tri_fidx[idx & ~kQueueTri];
             if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
         } else {
