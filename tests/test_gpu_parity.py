@@ -63,7 +63,7 @@ def test_hip_matches_golden(gpu, oracle, name):
         assert max_abs_diff(img, z["image"]) <= ATOL, (name, kern)
 
 
-@pytest.mark.parametrize("case", ["c1", "spheres2k", "mixed", "tris"])
+@pytest.mark.parametrize("case", ["c1", "spheres2k", "mixed", "tris", "tris20k"])
 def test_hip_matches_oracle_seeded(gpu, oracle, case):
     from rust_raytracing_amd import scenes
     objs, w, h, cfg = {
@@ -71,6 +71,7 @@ def test_hip_matches_oracle_seeded(gpu, oracle, case):
         "spheres2k": (scenes.compact(scenes.random_spheres(2000, 1), k=0.3), 96, 54, dict(rays_per_pixel=4, seed=42)),
         "mixed": (scenes.mixed_scene(60, 50, 2, seed=21), 64, 40, dict(rays_per_pixel=4, seed=3)),
         "tris": (scenes.light_every(scenes.compact(scenes.random_triangles(400, 5)), 3), 48, 32, dict(rays_per_pixel=3, seed=8)),
+        "tris20k": (scenes.random_triangles(20000, 6, box=0.3), 64, 36, dict(rays_per_pixel=2, seed=4)),   # C3 recipe, denser
     }[case]
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
     for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
@@ -467,6 +468,29 @@ def test_c4_shaped_band_of_one_rank(gpu, oracle):
         ref = oracle.render(osc, w, h, row_begin=y, row_stride=h)       # exactly one row
         assert max_abs_diff(got[k], ref[y]) <= ATOL
     assert got.mean() > 0.01
+
+
+def test_c5_shaped_rows_of_one_rank(gpu):
+    """BASELINE.json configs[4] is 1M triangles at 3840x2160 over 8 GPUs.  With the footprint tree the BVH kernel keeps the
+    reference's triangle semantics (no "geometric semantics" needed): rows of the band rank 5 of 8 would own,
+    1 spp, AUTO (= BVH, deep tree -> HBM stack spill variant) against the exhaustive f64 kernel bit for bit (the oracle
+    needs ~20 minutes per row at this triangle count; it pins the same kernels on the smaller meshes above)."""
+    import torch
+    from rust_raytracing_amd import scenes, tiles
+    objs = scenes.random_triangles(1000000, 3, box=2.0)
+    w, h, world, rank = 3840, 2160, 8, 5
+    rb, rs, n = tiles.rows_for_rank(h, rank, world)
+    out = {}
+    for kern in (gpu.RTX_KERNEL_AUTO, gpu.RTX_KERNEL_EXACT):
+        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=1, seed=42, kernel=kern), gpu.Camera(*scenes.CAMERA), objs).upload(0)
+        buf = torch.zeros((3, w, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(w, h, rb + 100 * rs, rs, 3, buf.data_ptr())       # rows 100..102 of the band
+        out[kern] = (buf.cpu().numpy(), st.segments, st.kernel)
+        hnd.close()
+    a, e = out[gpu.RTX_KERNEL_AUTO], out[gpu.RTX_KERNEL_EXACT]
+    assert a[2] == gpu.RTX_KERNEL_BVH
+    assert np.array_equal(a[0], e[0]) and a[1] == e[1]
+    assert a[0].mean() > 0.01
 
 
 def test_c2_full_size_properties(gpu, oracle):

@@ -45,6 +45,14 @@ for name, key in (("bvh", "c2_64spp_kernel4"), ("mixed", "c2_64spp_kernel2")):
                        "gathers and SoA slot loads.",
                "source": "profiles/%s_c2_64spp_pmc_hbm.csv" % tag}
 json.dump(tj, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+# the bench line of this run read the PREVIOUS traffic.json; the PMC passes of this very run (same box, same command)
+# are the figure that belongs to it
+bj = json.load(open(os.path.join(P, "%s_bench_n1.json" % tag)))
+if "c2_64spp_kernel4" in tj:
+    bj["roofline"]["traffic"] = tj["c2_64spp_kernel4"]["hbm_bytes_per_launch"]
+if "c2_64spp_kernel2" in tj and "lds_sweep" in bj:
+    bj["lds_sweep"]["roofline"]["traffic"] = tj["c2_64spp_kernel2"]["hbm_bytes_per_launch"]
+json.dump(bj, open(os.path.join(P, "%s_bench_n1.json" % tag), "w"))
 print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in tj.items()}))
 for l in open(stats).read().splitlines()[:4]:
     print(l[:230])
