@@ -45,16 +45,21 @@ enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_TRIANGLE = 2 };
 enum {
     RTX_KERNEL_AUTO  = 0,  /* RTX_KERNEL_BVH when a tree was built at upload (more than 4 finite spheres and/or more than
                               4 triangles with an (x, y) footprint) and at most 64 spheres/triangles stay outside it,
-                              else RTX_KERNEL_MIXED; all kernels produce the same bits, AUTO picks the fastest */
+                              (RTX_KERNEL_BVH_REGROUP instead when the tree holds a triangle mesh and the launch has
+                              at least 2^24 rays), else RTX_KERNEL_MIXED; all kernels produce the same bits, AUTO picks
+                              the fastest */
     RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
     RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
                               produces the same bits as RTX_KERNEL_EXACT */
     RTX_KERNEL_MIXED_VERIFY = 3, /* debug: MIXED that also runs the exact sweep per segment and counts
                               disagreements in RtxStats.filter_mismatches (must stay 0) */
-    RTX_KERNEL_BVH = 4     /* spheres and triangles found by traversal of a flat BVH built at upload (SURVEY 8f N2:
+    RTX_KERNEL_BVH = 4,    /* spheres and triangles found by traversal of a flat BVH built at upload (SURVEY 8f N2:
                               3-D sphere boxes; (x, y) footprints for triangles, which keeps the reference's phantom
                               hits), exact f64 leaf tests; planes and shapes outside the tree tested for every
                               segment; same bits as RTX_KERNEL_EXACT.  RtxStats.box_tests counts child boxes tested */
+    RTX_KERNEL_BVH_REGROUP = 5 /* RTX_KERNEL_BVH's tree and step under a different schedule: lanes whose traversal ended
+                              wait until enough of them can shade together, instead of every lane waiting for the
+                              wave's longest traversal; pays off on large triangle meshes; same bits */
 };
 
 /* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)

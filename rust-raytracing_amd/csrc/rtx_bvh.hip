@@ -1,7 +1,7 @@
 // rtx_bvh.hip -- trace_bvh_kernel: closest_object (scene.rs:243-251) by flat-BVH traversal over spheres and triangles.
 //
 // Persistent waves; each lane owns one ray for its whole life (ray state in registers).  A wave takes rays
-// from the global queue 512 at a time (one atomic per 512 rays) and hands them to idle lanes with
+// from the global queue 512 at a time (one atomic per rv.grab rays) and hands them to idle lanes with
 // ballot + mbcnt, so lanes whose path ended are refilled at once.  Per segment each lane walks the BVH with its
 // own LDS stack (depth-major layout: no bank conflicts).  Nodes are 4-wide (128 B: the boxes of up to four
 // children inline), so a step is ONE dependent fetch; children are visited nearest first and boxes whose entry
@@ -24,122 +24,6 @@
 #include "rtx_traverse.h"
 
 namespace rtx {
-
-namespace {
-
-#ifndef RTX_BVH_WPE
-#define RTX_BVH_WPE 4
-#endif
-constexpr int kBvhWavesPerSimd = RTX_BVH_WPE;     // = workgroups per CU (4 waves each)
-constexpr uint32_t kGrab = 512;            // rays a wave takes from the global queue per atomic
-
-__device__ __forceinline__ uint32_t bvh_mbcnt(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-}  // namespace
-
-// One traversal step of one lane: open wide node `node`, filter its leaf children into the candidate queue, push
-// the interior children still in reach (farthest first) and move to the nearest (or pop).  node == kNone afterwards
-// means the traversal is complete.  lds_stack has one row more than kBvh4StackEntries: the sink of the branch-free
-// pushes.
-template <bool TRIS, bool SPILL>
-__device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const LeafArrays &la, const Ray32 &q,
-                                         const FilterParams &fpar, const TriFilterParams &tpar, const RayX &rx, uint32_t &node,
-                                         uint32_t &sp, uint32_t &qcnt, bool &overflow, Hit &h, float &best_up,
-                                         uint32_t *lds_stack, uint32_t *lds_q, uint32_t tid, uint32_t *__restrict__ spill,
-                                         uint32_t spill_entries, size_t spill_stride, size_t glane,
-                                         uint32_t &nbox, uint32_t &nleaf, unsigned long long &exact)
-{
-    // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
-    const float4 *np = nodes + 8 * (size_t)node;
-    float4 ca[4], cb[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
-    float tc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) tc[c] = box_entry32(ca[c], cb[c], q, best_up);
-    nbox += 4;
-    // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
-    // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
-    // shape) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
-    uint32_t leafmask = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t count = __float_as_uint(cb[c].w);
-        if (tc[c] < __builtin_inff() && count - 1u < 0x1FFFFu) leafmask |= 1u << c;          // neither interior (0) nor empty (~0)
-    }
-    while (leafmask != 0u) {                  // one copy of the leaf code, however many of the four children are leaves
-        const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
-        leafmask &= leafmask - 1u;
-        const uint32_t first = __float_as_uint(c == 0 ? ca[0].w : (c == 1 ? ca[1].w : (c == 2 ? ca[2].w : ca[3].w)));
-        const uint32_t count = __float_as_uint(c == 0 ? cb[0].w : (c == 1 ? cb[1].w : (c == 2 ? cb[2].w : cb[3].w)));
-        const uint32_t n = count & 0xFFFFu;
-        for (uint32_t k = 0; k < n; ++k) {
-            bool cand;
-            uint32_t entry = (first + k) | kQueueTri;
-            if (TRIS && (count & kBvhTriLeaf)) {
-                const float4 A = la.tri_f32[2 * (size_t)(first + k)], B = la.tri_f32[2 * (size_t)(first + k) + 1];
-                cand = (int)tri_filter_sign(A, B, tpar) >= 0;                       // q may be above the footprint
-            } else {
-                const float4 rec = la.sphere_f32[first + k];
-                cand = (int)__float_as_uint(filter_disc1(rec, fpar)) >= 0;          // D >= 0: cannot be excluded
-                if (cand) entry = la.sphere_prims[first + k];
-            }
-            if (cand) {
-                if (qcnt == (uint32_t)kBvhQueue) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
-                lds_q[(size_t)qcnt * kBvhThreads + tid] = entry;
-                qcnt += 1;
-            }
-        }
-        nleaf += n;
-    }
-    // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
-    float key[4];
-    uint32_t lnk[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        key[c] = __float_as_uint(cb[c].w) == 0u ? tc[c] : __builtin_inff();     // (tc is already inf for a box out of reach)
-        lnk[c] = __float_as_uint(ca[c].w);
-    }
-#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
-    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
-#undef RTX_CSWAP
-    // push the farther ones (farthest first), descend into the nearest.  The keys are sorted, so the children to push
-    // are lnk[1..npush]; lnk[i] goes to row sp + npush - i, the others to the sink row -- three unconditional stores.
-    // (stack + queue = 39 words of LDS per lane, which is what 16 waves per CU leave; entries beyond the 30 in LDS go
-    // to the lane's column of the HBM spill area, which the launcher sizes from the tree's depth so that it cannot run
-    // out -- the exhaustive sweep after an overflow is only a guard)
-    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
-                           (key[3] < __builtin_inff() ? 1u : 0u);
-    if (sp + 3u <= (uint32_t)kBvh4StackEntries) {
-#pragma unroll
-        for (uint32_t i = 1; i <= 3; ++i) {
-            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)kBvh4StackEntries;
-            lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
-        }
-        sp += npush;
-    } else {
-#define RTX_PUSH(v)                                                                                      \
-        {                                                                                                \
-            if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
-            else if (SPILL && sp - (uint32_t)kBvh4StackEntries < spill_entries) {                        \
-                spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane] = (v); sp += 1; \
-            } else overflow = true;                                                                      \
-        }
-        if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
-        if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
-        if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
-#undef RTX_PUSH
-    }
-    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
-    if (node == kNone && sp != 0u) {
-        sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
-        node = (!SPILL || sp < (uint32_t)kBvh4StackEntries) ? lds_stack[(size_t)sp * kBvhThreads + tid]
-                                                : spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane];
-    }
-}
 
 // TRIS: the tree holds triangle leaves.  SPILL: the tree is deep enough that a stack may need more than the LDS
 // entries.  (Both only remove code: the spheres-only shallow-tree variant is what C2 runs.)
@@ -168,8 +52,8 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
     RayState r;
     uint32_t pl = 0, smp = 0;
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
+    unsigned long long wave_steps = 0;      // (-DRTX_BVH_STATS: traversal-loop iterations of the wave, reported via exact_tests)
 #ifdef RTX_BVH_STATS
-    unsigned long long wave_steps = 0;      // diagnostic: traversal-loop iterations of the wave (reported via exact_tests)
     unsigned long long cyc_trav = 0, cyc_other = 0, cyc_mark = __builtin_amdgcn_s_memtime();   // (reported via filter_tests / box_tests)
 #define RTX_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - cyc_mark; cyc_mark = now_; }
 #else
@@ -177,16 +61,16 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
 #endif
 
     for (;;) {
-        // ---- hand rays to idle lanes: ballot + prefix sum over the wave's local range, one atomic per 512 rays
+        // ---- hand rays to idle lanes: ballot + prefix sum over the wave's local range, one atomic per rv.grab rays
         const unsigned long long idle_mask = __ballot(!alive);
         if (idle_mask != 0ull) {
             if (wave_next >= wave_end && !queue_empty) {
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)kGrab);
+                if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)rv.grab);
                 base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
                        __builtin_amdgcn_readfirstlane((uint32_t)base);
                 wave_next = base;
-                wave_end = base + kGrab < rv.n_rays ? base + kGrab : rv.n_rays;
+                wave_end = base + rv.grab < rv.n_rays ? base + rv.grab : rv.n_rays;
                 if (base >= rv.n_rays) { queue_empty = true; wave_next = wave_end = 0; }
             }
             if (!alive && wave_next < wave_end) {
@@ -220,31 +104,27 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                                      __builtin_fabsf((float)r.pos.z));
             bool sweep_spheres = true;                   // shapes the tree did not cover get the exact test below
             uint32_t tri_sweep_from = 0;
-            if (sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit) {          // NaN origin -> exhaustive branch
-                Ray32 q;
-                make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
+            const bool in32 = sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit;          // NaN origin -> exhaustive branch
+            const bool in64 = !in32 && sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit * kBvhRange64;
+            if (in32 || in64) {
                 FilterParams fpar;
                 TriFilterParams tpar;
                 if (sv.bvh_flags & 1u) filter_from_ray(sv, r.pos, r.dir, fpar); else filter_idle(fpar);
                 if (TRIS && (sv.bvh_flags & 2u)) tri_filter_from_ray(sv, r.pos, r.dir, tpar); else tri_filter_idle(tpar);
-                float best_up = __builtin_inff();
-                uint32_t sp = 0, qcnt = 0, step = 0, nbox = 0, nleaf = 0;
                 bool overflow = false;
-                uint32_t node = 0;                       // wide node 0 is the root
                 RTX_MARK(cyc_other)
-                while (node != kNone) {
-#ifdef RTX_BVH_STATS
-                    { const unsigned long long am = __ballot(true); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) wave_steps += 1; }
-#endif
-                    bvh_step<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, node, sp, qcnt, overflow, h, best_up, &lds_stack[0][0], &lds_q[0][0],
-                                          tid, spill, spill_entries, spill_stride, glane, nbox, nleaf, exact);
-                    step += 1;
-                    if ((step & 3u) == 0u) flush_candidates<TRIS>(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
+                if (in32) {
+                    Ray32 q;
+                    make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
+                    bvh_traverse<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
+                                              spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, wave_steps);
+                } else {                              // origin far outside the scene: the same walk with an f64 slab test
+                    Ray64 q;
+                    make_ray64(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
+                    bvh_traverse<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
+                                              spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, wave_steps);
                 }
                 RTX_MARK(cyc_trav)
-                box_tests += nbox;
-                leaf_filters += nleaf;
-                flush_candidates<TRIS>(la, rx, &lds_q[0][0], tid, qcnt, h, best_up, exact);
                 if (!overflow) {                      // (a dropped subtree: every shape gets the exact test)
                     sweep_spheres = (sv.bvh_flags & 1u) == 0u;
                     tri_sweep_from = (sv.bvh_flags & 2u) ? sv.n_tri_tree : 0u;

@@ -57,6 +57,9 @@ struct RowsView {
     uint32_t sample_begin;         // first sample index of this batch
     uint32_t n_samples;            // samples in this batch
     uint64_t n_rays;               // npix * n_samples
+    uint32_t grab;                 // rays a wave of the BVH kernels takes from the global queue per atomic: 512 for big
+    uint32_t pad_;                 // launches (consecutive rays = neighbouring pixels), less when that would leave fewer
+                                   // than ~8 grabs per wave (the last grabs decide how long the slowest wave runs)
     // host-libm trig tables (scene.rs:214-220): sin/cos(fov*(x/w-0.5)) per column,
     // sin/cos(vfov*(y/h-0.5)) per LOCAL row
     const double *sin_x, *cos_x, *sin_y, *cos_y;

@@ -22,10 +22,17 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
 // BVH kernel: persistent waves, one ray per lane, per-lane stack traversal of the flat BVH (sphere boxes, triangle
 // footprints) with a conservative f32 slab test; leaves and the shapes outside the tree use the exact f64 tests.  work_counter: zeroed u64 ray-queue head.
 // spill: bvh_spill_bytes(sv, n_cus) bytes of device scratch for stack entries beyond the LDS stack (may be null when 0).
+uint32_t bvh_spill_entries(const SceneView &sv);
 size_t bvh_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                             double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                             hipStream_t stream);
+
+// The same traversal scheduled as a per-lane state machine (rtx_bvh_regroup.hip): lanes that finished their traversal
+// wait until enough of them can shade together instead of the whole wave waiting for its longest traversal.
+hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                    double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill,
+                                    int n_cus, hipStream_t stream);
 
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
 // sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.

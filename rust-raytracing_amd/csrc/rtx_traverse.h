@@ -1,4 +1,4 @@
-// rtx_traverse.h -- pieces of the flat-BVH traversal shared by trace_bvh_kernel and trace_pool_kernel.
+// rtx_traverse.h -- the flat-BVH traversal shared by trace_bvh_kernel and trace_bvh_regroup_kernel.
 #pragma once
 
 #include "rtx_device.h"
@@ -7,10 +7,16 @@ namespace rtx {
 
 constexpr int kBvhThreads = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr float kBvhRange64 = 134217728.0f;       // 2^27: origins up to this multiple of origin_limit walk the tree in f64
 
 // The ray as the slab test sees it: per axis inv = fl(1 / d) and noi = fl(-o * inv), so that the distance to the
 // plane x = b is one FMA, t = fl(b * inv + noi).
 struct Ray32 { float ix, iy, iz, nx, ny, nz; };
+// The same in f64, for rays whose origin is outside the range the f32 test is valid for (a bounce off one of the
+// reference's far phantom hits, a camera far from the scene): rounding noi in f64 moves the planes by 2^-53 |o|, which
+// the boxes' padding covers up to |o| <= 2^27 * origin_limit.  Without it such a ray would test every shape exactly --
+// 0.3 s for one segment over 500k triangles, while its wave and the launch wait.
+struct Ray64 { double ix, iy, iz, nx, ny, nz; };
 
 // |1/d| is clamped to inv_max (SceneView::bvh_inv_max, <= 1e30 and small enough that o * inv stays finite): an
 // axis the ray is (almost) parallel to then gives two huge finite distances of the right signs instead of inf / NaN.
@@ -48,6 +54,29 @@ __device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, c
     const float tf_hi = tf * (1.0f + 4.76837158e-7f);                   // an upper bound when tf >= 0 (else a miss anyway)
     const bool hit = (tn_lo <= tf_hi) && (tn_lo <= best_up);
     return hit ? tn_lo : __builtin_inff();      // the widened (conservative) entry distance
+}
+
+__device__ __forceinline__ void make_ray64(const V3 &pos, const V3 &dirn, double inv_max, Ray64 &r)
+{
+    double i;
+    i = 1.0 / dirn.x; if (!(fabs(i) <= inv_max)) i = copysign(inv_max, dirn.x); r.ix = i; r.nx = -pos.x * i;
+    i = 1.0 / dirn.y; if (!(fabs(i) <= inv_max)) i = copysign(inv_max, dirn.y); r.iy = i; r.ny = -pos.y * i;
+    i = 1.0 / dirn.z; if (!(fabs(i) <= inv_max)) i = copysign(inv_max, dirn.z); r.iz = i; r.nz = -pos.z * i;
+}
+
+// f64 slab test on the same f32 boxes (same widening, far more than the f64 roundings need); the entry distance is
+// returned as an f32 rounded DOWN, so the f32 ordering / pruning code of bvh_step is shared.
+__device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, const Ray64 &r, float best_up)
+{
+    const double x0 = __builtin_fma((double)lo.x, r.ix, r.nx), x1 = __builtin_fma((double)hi.x, r.ix, r.nx);
+    const double y0 = __builtin_fma((double)lo.y, r.iy, r.ny), y1 = __builtin_fma((double)hi.y, r.iy, r.ny);
+    const double z0 = __builtin_fma((double)lo.z, r.iz, r.nz), z1 = __builtin_fma((double)hi.z, r.iz, r.nz);
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), 0.0));
+    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+    const double tn_lo = tn * (1.0 - 4.76837158e-7);
+    const double tf_hi = tf * (1.0 + 4.76837158e-7);
+    const bool hit = (tn_lo <= tf_hi) && (tn_lo <= (double)best_up);
+    return hit ? __double2float_rd(tn_lo) : __builtin_inff();
 }
 
 // best (f64) rounded UP to f32 for the pruning comparison
@@ -93,5 +122,145 @@ __device__ __forceinline__ void flush_candidates(const LeafArrays &la, const Ray
     if (h.id != kNone) best_up = round_up32(h.t);
 }
 
+
+// ---- shared by trace_bvh_kernel (rtx_bvh.hip) and trace_bvh_regroup_kernel (rtx_bvh_regroup.hip) ----------------------
+#ifndef RTX_BVH_WPE
+#define RTX_BVH_WPE 4
+#endif
+constexpr int kBvhWavesPerSimd = RTX_BVH_WPE;     // = workgroups per CU (4 waves each)
+
+__device__ __forceinline__ uint32_t bvh_mbcnt(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// One traversal step of one lane: open wide node `node`, filter its leaf children into the candidate queue, push
+// the interior children still in reach (farthest first) and move to the nearest (or pop).  node == kNone afterwards
+// means the traversal is complete.  lds_stack has one row more than kBvh4StackEntries: the sink of the branch-free
+// pushes.
+template <bool TRIS, bool SPILL, class RAY>
+__device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const LeafArrays &la, const RAY &q,
+                                         const FilterParams &fpar, const TriFilterParams &tpar, const RayX &rx, uint32_t &node,
+                                         uint32_t &sp, uint32_t &qcnt, bool &overflow, Hit &h, float &best_up,
+                                         uint32_t *lds_stack, uint32_t *lds_q, uint32_t tid, uint32_t *__restrict__ spill,
+                                         uint32_t spill_entries, size_t spill_stride, size_t glane,
+                                         uint32_t &nbox, uint32_t &nleaf, unsigned long long &exact)
+{
+    // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
+    const float4 *np = nodes + 8 * (size_t)node;
+    float4 ca[4], cb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+    float tc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+    nbox += 4;
+    // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
+    // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
+    // shape) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
+    uint32_t leafmask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t count = __float_as_uint(cb[c].w);
+        if (tc[c] < __builtin_inff() && count - 1u < 0x1FFFFu) leafmask |= 1u << c;          // neither interior (0) nor empty (~0)
+    }
+    while (leafmask != 0u) {                  // one copy of the leaf code, however many of the four children are leaves
+        const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
+        leafmask &= leafmask - 1u;
+        const uint32_t first = __float_as_uint(c == 0 ? ca[0].w : (c == 1 ? ca[1].w : (c == 2 ? ca[2].w : ca[3].w)));
+        const uint32_t count = __float_as_uint(c == 0 ? cb[0].w : (c == 1 ? cb[1].w : (c == 2 ? cb[2].w : cb[3].w)));
+        const uint32_t n = count & 0xFFFFu;
+        for (uint32_t k = 0; k < n; ++k) {
+            bool cand;
+            uint32_t entry = (first + k) | kQueueTri;
+            if (TRIS && (count & kBvhTriLeaf)) {
+                const float4 A = la.tri_f32[2 * (size_t)(first + k)], B = la.tri_f32[2 * (size_t)(first + k) + 1];
+                cand = (int)tri_filter_sign(A, B, tpar) >= 0;                       // q may be above the footprint
+            } else {
+                const float4 rec = la.sphere_f32[first + k];
+                cand = (int)__float_as_uint(filter_disc1(rec, fpar)) >= 0;          // D >= 0: cannot be excluded
+                if (cand) entry = la.sphere_prims[first + k];
+            }
+            if (cand) {
+                if (qcnt == (uint32_t)kBvhQueue) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+                lds_q[(size_t)qcnt * kBvhThreads + tid] = entry;
+                qcnt += 1;
+            }
+        }
+        nleaf += n;
+    }
+    // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
+    float key[4];
+    uint32_t lnk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        key[c] = __float_as_uint(cb[c].w) == 0u ? tc[c] : __builtin_inff();     // (tc is already inf for a box out of reach)
+        lnk[c] = __float_as_uint(ca[c].w);
+    }
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    // push the farther ones (farthest first), descend into the nearest.  The keys are sorted, so the children to push
+    // are lnk[1..npush]; lnk[i] goes to row sp + npush - i, the others to the sink row -- three unconditional stores.
+    // (stack + queue = 39 words of LDS per lane, which is what 16 waves per CU leave; entries beyond the 30 in LDS go
+    // to the lane's column of the HBM spill area, which the launcher sizes from the tree's depth so that it cannot run
+    // out -- the exhaustive sweep after an overflow is only a guard)
+    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                           (key[3] < __builtin_inff() ? 1u : 0u);
+    if (sp + 3u <= (uint32_t)kBvh4StackEntries) {
+#pragma unroll
+        for (uint32_t i = 1; i <= 3; ++i) {
+            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)kBvh4StackEntries;
+            lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
+        }
+        sp += npush;
+    } else {
+#define RTX_PUSH(v)                                                                                      \
+        {                                                                                                \
+            if (sp < (uint32_t)kBvh4StackEntries) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
+            else if (SPILL && sp - (uint32_t)kBvh4StackEntries < spill_entries) {                        \
+                spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane] = (v); sp += 1; \
+            } else overflow = true;                                                                      \
+        }
+        if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+        if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+        if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
+    }
+    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
+        node = (!SPILL || sp < (uint32_t)kBvh4StackEntries) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)kBvh4StackEntries) * spill_stride + glane];
+    }
+}
+
+// A whole traversal of one lane's segment: steps until the stack is empty, the queued candidates' exact f64 tests
+// every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child, shape) under
+// divergence -- the pruning bound lags by at most 4 steps, which only costs visits.
+template <bool TRIS, bool SPILL, class RAY>
+__device__ __forceinline__ void bvh_traverse(const float4 *__restrict__ nodes, const LeafArrays &la, const RAY &q,
+                                             const FilterParams &fpar, const TriFilterParams &tpar, const RayX &rx,
+                                             bool &overflow, Hit &h, uint32_t *lds_stack, uint32_t *lds_q, uint32_t tid,
+                                             uint32_t *__restrict__ spill, uint32_t spill_entries, size_t spill_stride, size_t glane,
+                                             unsigned long long &box_tests, unsigned long long &leaf_filters, unsigned long long &exact,
+                                             unsigned long long &wave_steps)
+{
+    float best_up = __builtin_inff();
+    uint32_t sp = 0, qcnt = 0, step = 0, nbox = 0, nleaf = 0;
+    uint32_t node = 0;                       // wide node 0 is the root
+    while (node != kNone) {
+#ifdef RTX_BVH_STATS
+        { const unsigned long long am = __ballot(true); if ((tid & 63u) == (uint32_t)(__ffsll((long long)am) - 1)) wave_steps += 1; }
+#endif
+        bvh_step<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, node, sp, qcnt, overflow, h, best_up, lds_stack, lds_q, tid, spill,
+                              spill_entries, spill_stride, glane, nbox, nleaf, exact);
+        step += 1;
+        if ((step & 3u) == 0u) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+    }
+    box_tests += nbox;
+    leaf_filters += nleaf;
+    flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+}
 
 }  // namespace rtx

@@ -32,7 +32,7 @@ def gpu(rtx):
 
 
 def _kernels(rtx):
-    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH]
+    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP]
 
 
 # ---- device arithmetic ---------------------------------------------------------------------------
@@ -74,7 +74,7 @@ def test_hip_matches_oracle_seeded(gpu, oracle, case):
         "tris20k": (scenes.random_triangles(20000, 6, box=0.3), 64, 36, dict(rays_per_pixel=2, seed=4)),   # C3 recipe, denser
     }[case]
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP):
         scene = hip_scene(gpu, objs, kernel=kern, **cfg)
         img = scene.render(w, h)
         assert max_abs_diff(img, ref) <= ATOL, (case, kern)
@@ -162,7 +162,7 @@ def test_triangle_filter_classes_and_no_mismatch(gpu, oracle):
     w, h = 72, 48
     ref, seg = oracle_render(oracle, objs, w, h, want_segments=True, **cfg)
     assert ref.mean() > 0.01
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_AUTO):
         assert max_abs_diff(hip_render(gpu, objs, w, h, kernel=kern, **cfg), ref) <= ATOL
     hnd = hip_scene(gpu, objs, kernel=gpu.RTX_KERNEL_MIXED_VERIFY, **cfg).upload(0)
     buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
@@ -185,7 +185,7 @@ def test_bvh_triangle_footprint_tree_is_bit_identical_to_exact_kernel(gpu, n_tri
     objs = scenes.random_triangles(n_tris, 2)
     cam = gpu.Camera(*scenes.CAMERA)
     out = {}
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_AUTO):
         hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, kernel=kern), cam, objs).upload(0)
         buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
@@ -194,8 +194,10 @@ def test_bvh_triangle_footprint_tree_is_bit_identical_to_exact_kernel(gpu, n_tri
     a, b, c = out[gpu.RTX_KERNEL_EXACT], out[gpu.RTX_KERNEL_BVH], out[gpu.RTX_KERNEL_AUTO]
     assert a[0].mean() > 0.01 and np.isfinite(a[0]).all()
     assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    g = out[gpu.RTX_KERNEL_BVH_REGROUP]
+    assert np.array_equal(a[0], g[0]) and a[1] == g[1]
     assert b[2] < a[2] / 1000
-    assert c[3] == gpu.RTX_KERNEL_BVH and np.array_equal(a[0], c[0])       # AUTO picks the tree for triangle meshes
+    assert c[3] in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP) and np.array_equal(a[0], c[0])       # AUTO picks the tree for triangle meshes
 
 
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
@@ -208,7 +210,7 @@ def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
     for cam in (((8.0, 0.5, 6.0), (0.0, 0.0, -1.0), 1.2), ((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), 1e-9),
                 ((8.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1e-9), ((-5000.0, 30.0, 10.0), (1.0, 0.0, 0.0), 0.02)):
         ref = oracle_render(oracle, objs, 40, 24, cam=cam, **cfg)
-        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_MIXED):
+        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_MIXED):
             assert max_abs_diff(hip_render(gpu, objs, 40, 24, cam=cam, kernel=kern, **cfg), ref) <= ATOL, (cam, kern)
 
 
@@ -260,7 +262,7 @@ def test_fuzz_random_scenes_all_kernels_match_oracle(gpu, oracle):
         cfg = dict(rays_per_pixel=2, seed=it, max_bounces=int(rng.choice([0, 3, 10])))
         ref = oracle_render(oracle, objs, 20, 12, cam=cam, **cfg)
         nonblack += int(np.nanmax(ref) > 0) if ref.size else 0
-        for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH):
+        for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP):
             got = hip_render(gpu, objs, 20, 12, cam=cam, kernel=kern, **cfg)
             assert max_abs_diff(got, ref) <= ATOL, (it, kern, len(objs))
     assert nonblack >= 75
@@ -298,7 +300,7 @@ def test_candidate_queue_overflow_falls_back_to_exact_sweep(gpu, oracle):
     o[3]["emission_color"] = (1, 0.5, 0.25)
     cfg = dict(rays_per_pixel=4, seed=11)
     ref = oracle_render(oracle, o, 48, 32, **cfg)
-    for kern in (gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH):
+    for kern in (gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP):
         assert max_abs_diff(hip_render(gpu, o, 48, 32, kernel=kern, **cfg), ref) <= ATOL
 
 
@@ -449,7 +451,7 @@ def test_edge_scenes_match_oracle(gpu, oracle, name):
     objs, cam, cfg = _edge_scene(name)
     w, h = 40, 28
     ref, seg = oracle_render(oracle, objs, w, h, cam=cam, want_segments=True, **cfg)
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_AUTO):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_MIXED_VERIFY, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_AUTO):
         img = hip_render(gpu, objs, w, h, cam=cam, kernel=kern, **cfg)
         assert np.array_equal(np.isnan(img), np.isnan(ref)), (name, kern)
         scale = max(1.0, float(np.nanmax(np.abs(ref))) if np.isfinite(np.nanmax(np.abs(ref))) else 1.0)
@@ -542,7 +544,7 @@ def test_c5_shaped_rows_of_one_rank(gpu):
         out[kern] = (buf.cpu().numpy(), st.segments, st.kernel)
         hnd.close()
     a, e = out[gpu.RTX_KERNEL_AUTO], out[gpu.RTX_KERNEL_EXACT]
-    assert a[2] == gpu.RTX_KERNEL_BVH
+    assert a[2] in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP)
     assert np.array_equal(a[0], e[0]) and a[1] == e[1]
     assert a[0].mean() > 0.01
 
