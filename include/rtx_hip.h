@@ -45,9 +45,8 @@ enum { RTX_SPHERE = 0, RTX_PLANE = 1, RTX_TRIANGLE = 2 };
 enum {
     RTX_KERNEL_AUTO  = 0,  /* RTX_KERNEL_BVH when a tree was built at upload (more than 4 finite spheres and/or more than
                               4 triangles with an (x, y) footprint) and at most 64 spheres/triangles stay outside it,
-                              (RTX_KERNEL_BVH_REGROUP instead when the tree holds a triangle mesh and the launch has
-                              at least 2^24 rays), else RTX_KERNEL_MIXED; all kernels produce the same bits, AUTO picks
-                              the fastest */
+                              (RTX_KERNEL_BVH_REGROUP instead when the tree holds a triangle mesh: >= 1024 triangles),
+                              else RTX_KERNEL_MIXED; all kernels produce the same bits, AUTO picks the fastest */
     RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
     RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
                               produces the same bits as RTX_KERNEL_EXACT */

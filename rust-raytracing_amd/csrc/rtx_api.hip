@@ -441,15 +441,15 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     }
     // AUTO: a BVH kernel when a tree was built at upload and few shapes stay outside it (those are tested for every
     // segment in f64), else the LDS sweep with its sphere and triangle filters.  Which BVH kernel: lock-step waves for
-    // sphere scenes; the regrouping schedule when the tree holds a triangle mesh and the launch is big enough to keep
-    // its lanes fed (measured: C3 at 16 spp 108 vs 79 Mrays/s, C5 band 14.0 vs 8.9; C2 719 vs 1343; C3 at 4 spp 64 vs 69)
+    // sphere scenes; the regrouping schedule when the tree holds a triangle mesh (measured, regroup vs lock-step:
+    // C3 at 1 / 16 spp 116 / 129 vs 81 / 86 Mrays/s, C5 band at 16 spp 32.4 vs 11.4; C2 752 vs 1337)
     const uint64_t outside_tree = ((h->sv.bvh_flags & 1u) ? 0u : h->sv.n_spheres) +
                                   (uint64_t)(h->sv.n_tri_filter - h->sv.n_tri_tree);
     uint32_t kernel = h->cfg.kernel;
     if (kernel == RTX_KERNEL_AUTO) {
         if (h->sv.n_bvh_nodes != 0 && outside_tree <= 64) {
             const bool mesh = (h->sv.bvh_flags & 2u) != 0u && h->sv.n_tri_tree >= 1024u;
-            kernel = mesh && (uint64_t)npix * batch >= (1ull << 24) ? RTX_KERNEL_BVH_REGROUP : RTX_KERNEL_BVH;
+            kernel = mesh ? RTX_KERNEL_BVH_REGROUP : RTX_KERNEL_BVH;
         } else {
             kernel = RTX_KERNEL_MIXED;
         }

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
 }
 
 #ifndef RTX_BVH_THRESH
-#define RTX_BVH_THRESH 8
+#define RTX_BVH_THRESH 16
 #endif
 
 hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
