@@ -528,6 +528,11 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         rv.sample_begin = (uint32_t)s0;
         rv.n_samples = (uint32_t)ns;
         rv.n_rays = (uint64_t)npix * ns;
+        rv.tiles_x = 0;
+        if ((kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) && !std::getenv("RTX_HIP_NO_TILES")) {
+            rv.tiles_x = (width + 7u) / 8u;
+            rv.n_rays = (uint64_t)rv.tiles_x * ((n_rows + 7u) / 8u) * 64u * ns;        // the padded tile grid
+        }
         {
             const uint64_t per_wave = rv.n_rays / ((uint64_t)h->n_cus * 16u * 8u);       // 16 resident waves per CU
             rv.grab = (uint32_t)(per_wave >= 512 ? 512 : (per_wave <= 64 ? 64 : (per_wave & ~(uint64_t)63)));

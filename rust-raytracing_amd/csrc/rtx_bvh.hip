@@ -75,8 +75,12 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
             }
             if (!alive && wave_next < wave_end) {
                 const unsigned long long my = wave_next + bvh_mbcnt(idle_mask);
-                if (my < wave_end) {
-                    ray_index_to_pixel(rv, my, pl, smp);
+                bool valid = my < wave_end;
+                if (valid) {
+                    if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
+                    else ray_index_to_pixel(rv, my, pl, smp);
+                }
+                if (valid) {
                     gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
                     alive = true;
                     if (sv.n_objects == 0) {                                      // scene.rs:224-226

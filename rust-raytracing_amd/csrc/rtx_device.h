@@ -58,8 +58,9 @@ struct RowsView {
     uint32_t n_samples;            // samples in this batch
     uint64_t n_rays;               // npix * n_samples
     uint32_t grab;                 // rays a wave of the BVH kernels takes from the global queue per atomic: 512 for big
-    uint32_t pad_;                 // launches (consecutive rays = neighbouring pixels), less when that would leave fewer
-                                   // than ~8 grabs per wave (the last grabs decide how long the slowest wave runs)
+    uint32_t tiles_x;              // launches, less when that would leave fewer than ~8 grabs per wave (the last grabs
+                                   // decide how long the slowest wave runs).  tiles_x != 0: the BVH kernels' ray index
+                                   // runs over 8x8 pixel tiles (a wave's 64 rays = one tile), n_rays counts the padded grid
     // host-libm trig tables (scene.rs:214-220): sin/cos(fov*(x/w-0.5)) per column,
     // sin/cos(vfov*(y/h-0.5)) per LOCAL row
     const double *sin_x, *cos_x, *sin_y, *cos_y;
@@ -104,6 +105,21 @@ __device__ __forceinline__ void ray_index_to_pixel(const RowsView &rv, uint64_t 
 {
     s_local = (uint32_t)(i / rv.npix);
     pl = (uint32_t)(i - (uint64_t)s_local * rv.npix);
+}
+
+// The same over 8x8 pixel tiles: 64 consecutive indices = one tile of one sample (more coherent primary rays than a
+// 64x1 strip: shared nodes, similar traversal lengths).  Returns false for the padding of partial tiles.
+__device__ __forceinline__ bool ray_index_to_pixel_tiled(const RowsView &rv, uint64_t i, uint32_t &pl, uint32_t &s_local)
+{
+    const uint32_t tiles_y = (rv.n_rows + 7u) >> 3;
+    const uint64_t per_sample = (uint64_t)rv.tiles_x * tiles_y * 64u;
+    s_local = (uint32_t)(i / per_sample);
+    const uint32_t r = (uint32_t)(i - (uint64_t)s_local * per_sample);
+    const uint32_t t = r >> 6, j = r & 63u;
+    const uint32_t ty = t / rv.tiles_x, tx = t - ty * rv.tiles_x;
+    const uint32_t x = tx * 8u + (j & 7u), k = ty * 8u + (j >> 3);
+    pl = k * rv.width + x;
+    return x < rv.width && k < rv.n_rows;
 }
 
 // render_pixel's per-sample prologue (scene.rs:196-207) + get_ray_dir (scene.rs:213-222).
