@@ -339,6 +339,10 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     }
     h->sv.n_tri_tree = bvh.has_tris ? (uint32_t)plain_recs.size() : 0u;
     for (const TriRec &r : always_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
+    if (!tri32.empty()) {                       // one pad record: bvh_step reads records in pairs
+        tri32.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+        tri32.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    }
     h->sv.n_tri_filter = (uint32_t)tri_fidx.size();
     h->sv.tri_extent = tri_extent;
     h->sv.n_objects = (uint32_t)n;

@@ -170,21 +170,30 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
         const uint32_t first = __float_as_uint(c == 0 ? ca[0].w : (c == 1 ? ca[1].w : (c == 2 ? ca[2].w : ca[3].w)));
         const uint32_t count = __float_as_uint(c == 0 ? cb[0].w : (c == 1 ? cb[1].w : (c == 2 ? cb[2].w : cb[3].w)));
         const uint32_t n = count & 0xFFFFu;
-        for (uint32_t k = 0; k < n; ++k) {
-            bool cand;
-            uint32_t entry = (first + k) | kQueueTri;
-            if (TRIS && (count & kBvhTriLeaf)) {
-                const float4 A = la.tri_f32[2 * (size_t)(first + k)], B = la.tri_f32[2 * (size_t)(first + k) + 1];
-                cand = (int)tri_filter_sign(A, B, tpar) >= 0;                       // q may be above the footprint
-            } else {
-                const float4 rec = la.sphere_f32[first + k];
-                cand = (int)__float_as_uint(filter_disc1(rec, fpar)) >= 0;          // D >= 0: cannot be excluded
-                if (cand) entry = la.sphere_prims[first + k];
+        if (TRIS && (count & kBvhTriLeaf)) {
+            // two records per round, their four loads in flight together (the array is padded by one record, so the
+            // second pair may be read even when it belongs to the next leaf)
+            for (uint32_t k = 0; k < n; k += 2u) {
+                const float4 *rp = la.tri_f32 + 2 * (size_t)(first + k);
+                const float4 A0 = rp[0], B0 = rp[1], A1 = rp[2], B1 = rp[3];
+                uint32_t m = (int)tri_filter_sign(A0, B0, tpar) >= 0 ? 1u : 0u;      // q may be above the footprint
+                if (k + 1u < n && (int)tri_filter_sign(A1, B1, tpar) >= 0) m |= 2u;
+                while (m != 0u) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    if (qcnt == (uint32_t)kBvhQueue) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+                    lds_q[(size_t)qcnt * kBvhThreads + tid] = (first + k + j) | kQueueTri;
+                    qcnt += 1;
+                }
             }
-            if (cand) {
-                if (qcnt == (uint32_t)kBvhQueue) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
-                lds_q[(size_t)qcnt * kBvhThreads + tid] = entry;
-                qcnt += 1;
+        } else {
+            for (uint32_t k = 0; k < n; ++k) {
+                const float4 rec = la.sphere_f32[first + k];
+                if ((int)__float_as_uint(filter_disc1(rec, fpar)) >= 0) {            // D >= 0: cannot be excluded
+                    if (qcnt == (uint32_t)kBvhQueue) flush_candidates<TRIS>(la, rx, lds_q, tid, qcnt, h, best_up, exact);
+                    lds_q[(size_t)qcnt * kBvhThreads + tid] = la.sphere_prims[first + k];
+                    qcnt += 1;
+                }
             }
         }
         nleaf += n;
