@@ -572,3 +572,30 @@ def test_c2_full_size_properties(gpu, oracle):
     ref = oracle.render(osc, w, h, row_begin=100, row_stride=216)
     assert max_abs_diff(a[100::216], ref[100::216]) <= ATOL
     assert a.mean() > 0.01
+
+
+def test_bench_line_contract(gpu):
+    """bench.py at a reduced sample count: one JSON line with the contract's keys, the roofline and cpu_baseline objects,
+    and the two kernels' frames bit-identical."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--spp", "2",
+                          "--cpu-sample", "48x16x1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["value"] > 0
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert d["lds_sweep"]["image_identical_to_value_kernel"] is True
+
