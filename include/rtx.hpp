@@ -245,6 +245,11 @@ public:
         return packed;
     }
 
+    class Resident;
+    // Row N4 of SURVEY 8f (the use-case of the crate's wgpu path, gpu_state/buffer.rs:69-115): the scene stays on
+    // `device`; camera / config changes do not re-upload it.
+    Resident upload(int device = 0) const;
+
 private:
     RtxScene to_c(const std::vector<RtxObject> &packed) const
     {
@@ -262,5 +267,59 @@ private:
         return sc;
     }
 };
+
+// A scene resident in the HBM of one GPU (rtx_scene_upload ... rtx_scene_free).  Output goes to DEVICE memory the
+// caller owns (h*w*3 doubles for a full frame), on the HIP stream it names; a row band per call is what one rank of
+// a multi-GPU job renders.
+class Scene::Resident {
+public:
+    Resident(const Resident &) = delete;
+    Resident &operator=(const Resident &) = delete;
+    Resident(Resident &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    ~Resident() { if (h_) rtx_scene_free(h_); }
+
+    void set_camera(const Camera &camera)                              // Camera::set_position / set_direction, camera.rs:35-40
+    {
+        const RtxCamera c = camera.to_c();
+        check(rtx_scene_set_camera(h_, &c));
+    }
+    void set_config(const Config &config)
+    {
+        RtxConfig c{};
+        c.rays_per_pixel = config.rays_per_pixel; c.max_bounces = config.max_bounces;
+        c.focal_length = config.focal_length; c.focal_offset = config.focal_offset; c.non_focal_offset = config.non_focal_offset;
+        c.seed = config.seed; c.kernel = config.kernel;
+        check(rtx_scene_set_config(h_, &c));
+    }
+    // rows row_begin, row_begin + row_stride, ... (n_rows of them) of the width x height image -> d_out_rgb[n_rows][width][3]
+    RtxStats render_rows(std::size_t width, std::size_t height, std::size_t row_begin, std::size_t row_stride, std::size_t n_rows,
+                         double *d_out_rgb, void *hip_stream = nullptr)
+    {
+        RtxStats st{};
+        check(rtx_render_rows(h_, (uint32_t)width, (uint32_t)height, (uint32_t)row_begin, (uint32_t)row_stride, (uint32_t)n_rows,
+                              d_out_rgb, hip_stream, &st));
+        return st;
+    }
+    RtxStats render(std::size_t width, std::size_t height, double *d_out_rgb, void *hip_stream = nullptr)
+    {
+        return render_rows(width, height, 0, 1, height, d_out_rgb, hip_stream);
+    }
+
+private:
+    friend class Scene;
+    explicit Resident(RtxSceneHandle h) : h_(h) {}
+    static void check(int32_t rc) { if (rc != RTX_OK) throw Panic(rc, rtx_last_error()); }
+    RtxSceneHandle h_;
+};
+
+inline Scene::Resident Scene::upload(int device) const
+{
+    std::vector<RtxObject> packed = pack();
+    RtxScene sc = to_c(packed);
+    RtxSceneHandle h = nullptr;
+    int32_t rc = rtx_scene_upload(&sc, device, &h);
+    if (rc != RTX_OK) throw Panic(rc, rtx_last_error());
+    return Resident(h);
+}
 
 }  // namespace rtx

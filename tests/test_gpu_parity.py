@@ -499,6 +499,31 @@ def test_cpp_host_api_example(gpu, oracle, tmp_path):
     assert np.array_equal(np.fromfile(rgb8, dtype=np.uint8).reshape(30, 40, 3), oracle.quantize_image(img))
 
 
+def test_cpp_resident_scene_camera_updates(gpu, oracle, tmp_path):
+    """examples/orbit_camera.cpp: rtx::Scene::upload -> Resident::set_camera / render into device memory, four frames of
+    one resident scene (row N4), each against the oracle with the same camera."""
+    from rust_raytracing_amd import scenes
+    exe = os.path.join(ROOT, "examples", "orbit_camera")
+    if not os.path.exists(exe):
+        pytest.fail("examples/orbit_camera not built; run __graft_entry__.build()")
+    out = str(tmp_path / "frames.f64")
+    w, h, spp, frames = 40, 30, 2, 4
+    subprocess.check_call([exe, str(w), str(h), str(spp), str(frames), out])
+    got = np.fromfile(out, dtype=np.float64).reshape(frames, h, w, 3)
+    objs = np.zeros(4, dtype=gpu.OBJECT_DTYPE)
+    objs[:3] = scenes.three_spheres()
+    objs[3]["kind"] = 2
+    objs[3]["geom"] = (8, -3, -1, 8, 3, -1, 8, 0, 2.5)
+    objs[3]["base_color"] = (0.2, 0.6, 0.9)
+    objs[3]["roughness"] = 1.0
+    for k in range(frames):
+        pos = (0.25 * k, -1.5 + 0.75 * k, 0.1 * k)
+        cam = (pos, (6.0 - pos[0], 0.0 - pos[1], 0.5 - pos[2]), math.pi / 2)
+        ref = oracle_render(oracle, objs, w, h, cam=cam, rays_per_pixel=spp, seed=42)
+        assert max_abs_diff(got[k], ref) <= ATOL, k
+    assert got.mean() > 0.01 and not np.array_equal(got[0], got[1])
+
+
 # ---- BASELINE.json's full-size workload through size-independent properties ----------------------------------
 def test_c4_shaped_band_of_one_rank(gpu, oracle):
     """BASELINE.json configs[3] is 3840x2160 over 8 GPUs: render the band rank 3 of 8 would own (270 interleaved rows,
