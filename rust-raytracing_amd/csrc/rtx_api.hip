@@ -358,6 +358,7 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
 
     h->sv.n_bvh_nodes = (uint32_t)bvh4.nodes.size();
     h->sv.bvh_depth = (uint32_t)bvh4.depth;
+    h->sv.bvh_root = bvh4.root;
     h->sv.bvh_origin_limit = (float)bvh.origin_limit;
     h->sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
     h->sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);

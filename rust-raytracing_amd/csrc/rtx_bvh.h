@@ -282,6 +282,7 @@ inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::ve
     out.origin_limit = 4.0 * scale + 1.0;
     out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
     if (!(out.origin_limit < 1.0e28)) return BvhBuild();
+    if (sphere_boxes.size() + tri_boxes.size() >= 0x20000000ull) return BvhBuild();          // node indices must stay below kBvhFlatNode
     if (tri_leaf_size < 1) tri_leaf_size = 1;
     if (tri_leaf_size > (uint32_t)kBvhTriLeafMax) tri_leaf_size = (uint32_t)kBvhTriLeafMax;
     out.nodes.reserve(2 * (sphere_boxes.size() + tri_boxes.size()) + 4);
@@ -318,9 +319,16 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 
 constexpr int kBvh4StackEntries = 30;     // per-ray traversal stack (LDS); deeper trees may overflow it (handled)
 
+// Footprint nodes (every child box unbounded in z: the triangle sub-tree) use a flat layout in the same 128 bytes,
+// which needs 6 of the 8 loads and a 2-D slab test:
+//   a[c] = {lo.x, lo.y, hi.x, hi.y} of child c;  b[0] = the four links, b[1] = the four counts;  b[2], b[3] unused.
+// A link (or the root) that points to such a node has kBvhFlatNode set.
+constexpr uint32_t kBvhFlatNode = 0x80000000u;
+
 struct Bvh4Build {
     std::vector<Bvh4Node> nodes;
     int depth = 0;
+    uint32_t root = 0;                    // 0, or kBvhFlatNode when the root itself is a footprint node
 };
 
 inline float u32_as_f32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
@@ -335,9 +343,15 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
         if (!std::isfinite(dz)) return dx + dy;                  // footprint node: what a 2-D ray can hit is its perimeter
         return dx * dy + dy * dz + dz * dx;
     };
+    const bool joint = b2.has_spheres && b2.has_tris;              // binary node 0 then joins the two sub-trees
+    auto flat = [&](uint32_t bin) {                                // a node of the triangle sub-tree
+        const BvhNode &n = b2.nodes[bin];
+        return std::isinf(n.lo[2]) && std::isinf(n.hi[2]) && !(joint && bin == 0u);
+    };
     struct Task { uint32_t bin; uint32_t wide; int depth; };
     std::vector<Task> todo;
     out.nodes.emplace_back();
+    out.root = flat(0u) ? kBvhFlatNode : 0u;
     todo.push_back({0u, 0u, 1});
     while (!todo.empty()) {
         const Task t = todo.back();
@@ -362,6 +376,8 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
             }
         }
         Bvh4Node w;
+        const bool wflat = flat(t.bin);
+        uint32_t links[4] = { 0u, 0u, 0u, 0u }, counts[4] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
         for (int c = 0; c < 4; ++c) {
             if (c < nk) {
                 const BvhNode &n = b2.nodes[kids[c]];
@@ -370,13 +386,26 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
                     link = (uint32_t)out.nodes.size();
                     out.nodes.emplace_back();
                     todo.push_back({kids[c], link, t.depth + 1});
+                    if (flat(kids[c])) link |= kBvhFlatNode;
                 }
-                w.a[c] = make_float4(n.lo[0], n.lo[1], n.lo[2], u32_as_f32(link));
-                w.b[c] = make_float4(n.hi[0], n.hi[1], n.hi[2], u32_as_f32(count));
+                links[c] = link; counts[c] = count;
+                if (wflat) w.a[c] = make_float4(n.lo[0], n.lo[1], n.hi[0], n.hi[1]);
+                else {
+                    w.a[c] = make_float4(n.lo[0], n.lo[1], n.lo[2], u32_as_f32(link));
+                    w.b[c] = make_float4(n.hi[0], n.hi[1], n.hi[2], u32_as_f32(count));
+                }
+            } else if (wflat) {
+                w.a[c] = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
             } else {
                 w.a[c] = make_float4(INFINITY, INFINITY, INFINITY, u32_as_f32(0u));
                 w.b[c] = make_float4(-INFINITY, -INFINITY, -INFINITY, u32_as_f32(0xFFFFFFFFu));
             }
+        }
+        if (wflat) {
+            w.b[0] = make_float4(u32_as_f32(links[0]), u32_as_f32(links[1]), u32_as_f32(links[2]), u32_as_f32(links[3]));
+            w.b[1] = make_float4(u32_as_f32(counts[0]), u32_as_f32(counts[1]), u32_as_f32(counts[2]), u32_as_f32(counts[3]));
+            w.b[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            w.b[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         out.nodes[t.wide] = w;
     }

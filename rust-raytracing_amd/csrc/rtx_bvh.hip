@@ -120,12 +120,12 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                 if (in32) {
                     Ray32 q;
                     make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
-                    bvh_traverse<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
+                    bvh_traverse<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, sv.bvh_root, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
                                               spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, wave_steps);
                 } else {                              // origin far outside the scene: the same walk with an f64 slab test
                     Ray64 q;
                     make_ray64(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
-                    bvh_traverse<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
+                    bvh_traverse<TRIS, SPILL>(nodes, la, q, fpar, tpar, rx, sv.bvh_root, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
                                               spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, wave_steps);
                 }
                 RTX_MARK(cyc_trav)

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
             }
             if (tree_used) {
                 make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
-                node = 0;                        // wide node 0 is the root
+                node = sv.bvh_root;              // wide node 0 (flagged when it is a footprint node)
                 state = S_TRAV;
             } else {
                 if (sv.n_bvh_nodes != 0 && omax <= sv.bvh_origin_limit * kBvhRange64) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
                     Ray64 q64;
                     make_ray64(r.pos, rx.dirn, (double)sv.bvh_inv_max, q64);
                     unsigned long long unused_steps = 0;
-                    bvh_traverse<TRIS, SPILL>(nodes, la, q64, fpar, tpar, rx, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
+                    bvh_traverse<TRIS, SPILL>(nodes, la, q64, fpar, tpar, rx, sv.bvh_root, overflow, h, &lds_stack[0][0], &lds_q[0][0], tid, spill,
                                               spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, unused_steps);
                     tree_used = true;
                 }

@@ -42,7 +42,9 @@ struct SceneView {
     const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
     const float4   *bvh_leaf_f32;              // per sphere leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
     uint32_t        n_bvh_nodes;
+    uint32_t        bvh_root;                  // where a traversal starts: 0, or kBvhFlatNode when node 0 is a footprint node
     uint32_t        bvh_depth;
+    uint32_t        pad2_;
     float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
     uint32_t        bvh_flags;                 // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
     uint32_t        n_tri_tree;                // triangle filter records [0, n_tri_tree) are in leaf order (a triangle leaf's link

@@ -79,6 +79,31 @@ __device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, c
     return hit ? __double2float_rd(tn_lo) : __builtin_inff();
 }
 
+// The same tests for a footprint node's child {lo.x, lo.y, hi.x, hi.y} (rtx_bvh.h): two slabs.
+__device__ __forceinline__ float rect_entry32(const float4 r4, const Ray32 &r, float best_up)
+{
+    const float x0 = __builtin_fmaf(r4.x, r.ix, r.nx), x1 = __builtin_fmaf(r4.z, r.ix, r.nx);
+    const float y0 = __builtin_fmaf(r4.y, r.iy, r.ny), y1 = __builtin_fmaf(r4.w, r.iy, r.ny);
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), 0.0f);
+    const float tf = fminf(fmaxf(x0, x1), fmaxf(y0, y1));
+    const float tn_lo = tn * (1.0f - 4.76837158e-7f);
+    const float tf_hi = tf * (1.0f + 4.76837158e-7f);
+    const bool hit = (tn_lo <= tf_hi) && (tn_lo <= best_up);
+    return hit ? tn_lo : __builtin_inff();
+}
+
+__device__ __forceinline__ float rect_entry32(const float4 r4, const Ray64 &r, float best_up)
+{
+    const double x0 = __builtin_fma((double)r4.x, r.ix, r.nx), x1 = __builtin_fma((double)r4.z, r.ix, r.nx);
+    const double y0 = __builtin_fma((double)r4.y, r.iy, r.ny), y1 = __builtin_fma((double)r4.w, r.iy, r.ny);
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), 0.0);
+    const double tf = fmin(fmax(x0, x1), fmax(y0, y1));
+    const double tn_lo = tn * (1.0 - 4.76837158e-7);
+    const double tf_hi = tf * (1.0 + 4.76837158e-7);
+    const bool hit = (tn_lo <= tf_hi) && (tn_lo <= (double)best_up);
+    return hit ? __double2float_rd(tn_lo) : __builtin_inff();
+}
+
 // best (f64) rounded UP to f32 for the pruning comparison
 __device__ __forceinline__ float round_up32(double best)
 {
@@ -146,29 +171,44 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
                                          uint32_t spill_entries, size_t spill_stride, size_t glane,
                                          uint32_t &nbox, uint32_t &nleaf, unsigned long long &exact)
 {
-    // one 128-byte fetch: the boxes of up to four children (rtx_bvh.h Bvh4Node)
-    const float4 *np = nodes + 8 * (size_t)node;
-    float4 ca[4], cb[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+    // one 128-byte node: the boxes of up to four children (rtx_bvh.h Bvh4Node; 8 loads), or -- in the triangle
+    // sub-tree -- their footprint rectangles, links and counts (6 loads)
+    const float4 *np = nodes + 8 * (size_t)(node & ~kBvhFlatNode);
     float tc[4];
+    uint32_t lnk[4], cnt[4];
+    if (TRIS && (node & kBvhFlatNode)) {
+        float4 rc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+        for (int c = 0; c < 4; ++c) rc[c] = np[c];
+        const float4 lk = np[4], ct = np[5];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tc[c] = rect_entry32(rc[c], q, best_up);
+        lnk[0] = __float_as_uint(lk.x); lnk[1] = __float_as_uint(lk.y); lnk[2] = __float_as_uint(lk.z); lnk[3] = __float_as_uint(lk.w);
+        cnt[0] = __float_as_uint(ct.x); cnt[1] = __float_as_uint(ct.y); cnt[2] = __float_as_uint(ct.z); cnt[3] = __float_as_uint(ct.w);
+    } else {
+        float4 ca[4], cb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+            lnk[c] = __float_as_uint(ca[c].w);
+            cnt[c] = __float_as_uint(cb[c].w);
+        }
+    }
     nbox += 4;
     // leaf children that the ray enters: f32 filter now, survivors are queued; the exact f64 tests run
     // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child,
     // shape) under divergence.  The pruning bound lags by at most 4 steps, which only costs visits.
     uint32_t leafmask = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t count = __float_as_uint(cb[c].w);
-        if (tc[c] < __builtin_inff() && count - 1u < 0x1FFFFu) leafmask |= 1u << c;          // neither interior (0) nor empty (~0)
-    }
+    for (int c = 0; c < 4; ++c)
+        if (tc[c] < __builtin_inff() && cnt[c] - 1u < 0x1FFFFu) leafmask |= 1u << c;          // neither interior (0) nor empty (~0)
     while (leafmask != 0u) {                  // one copy of the leaf code, however many of the four children are leaves
         const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
         leafmask &= leafmask - 1u;
-        const uint32_t first = __float_as_uint(c == 0 ? ca[0].w : (c == 1 ? ca[1].w : (c == 2 ? ca[2].w : ca[3].w)));
-        const uint32_t count = __float_as_uint(c == 0 ? cb[0].w : (c == 1 ? cb[1].w : (c == 2 ? cb[2].w : cb[3].w)));
+        const uint32_t first = c == 0 ? lnk[0] : (c == 1 ? lnk[1] : (c == 2 ? lnk[2] : lnk[3]));
+        const uint32_t count = c == 0 ? cnt[0] : (c == 1 ? cnt[1] : (c == 2 ? cnt[2] : cnt[3]));
         const uint32_t n = count & 0xFFFFu;
         if (TRIS && (count & kBvhTriLeaf)) {
             // two records per round, their four loads in flight together (the array is padded by one record, so the
@@ -200,12 +240,8 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
     }
     // interior children still in reach, nearest first: keys = entry distance (inf = not to be visited)
     float key[4];
-    uint32_t lnk[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        key[c] = __float_as_uint(cb[c].w) == 0u ? tc[c] : __builtin_inff();     // (tc is already inf for a box out of reach)
-        lnk[c] = __float_as_uint(ca[c].w);
-    }
+    for (int c = 0; c < 4; ++c) key[c] = cnt[c] == 0u ? tc[c] : __builtin_inff();     // (tc is already inf for a box out of reach)
 #define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
     RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
@@ -250,14 +286,14 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
 template <bool TRIS, bool SPILL, class RAY>
 __device__ __forceinline__ void bvh_traverse(const float4 *__restrict__ nodes, const LeafArrays &la, const RAY &q,
                                              const FilterParams &fpar, const TriFilterParams &tpar, const RayX &rx,
-                                             bool &overflow, Hit &h, uint32_t *lds_stack, uint32_t *lds_q, uint32_t tid,
+                                             uint32_t root, bool &overflow, Hit &h, uint32_t *lds_stack, uint32_t *lds_q, uint32_t tid,
                                              uint32_t *__restrict__ spill, uint32_t spill_entries, size_t spill_stride, size_t glane,
                                              unsigned long long &box_tests, unsigned long long &leaf_filters, unsigned long long &exact,
                                              unsigned long long &wave_steps)
 {
     float best_up = __builtin_inff();
     uint32_t sp = 0, qcnt = 0, step = 0, nbox = 0, nleaf = 0;
-    uint32_t node = 0;                       // wide node 0 is the root
+    uint32_t node = root;                    // wide node 0 (with kBvhFlatNode when it is a footprint node)
     while (node != kNone) {
 #ifdef RTX_BVH_STATS
         { const unsigned long long am = __ballot(true); if ((tid & 63u) == (uint32_t)(__ffsll((long long)am) - 1)) wave_steps += 1; }
