@@ -317,7 +317,10 @@ struct Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 
-constexpr int kBvh4StackEntries = 30;     // per-ray traversal stack (LDS); deeper trees may overflow it (handled)
+#ifndef RTX_BVH_STACK
+#define RTX_BVH_STACK 30
+#endif
+constexpr int kBvh4StackEntries = RTX_BVH_STACK;     // per-ray traversal stack (LDS); deeper trees may overflow it (handled)
 
 // Footprint nodes (every child box unbounded in z: the triangle sub-tree) use a flat layout in the same 128 bytes,
 // which needs 6 of the 8 loads and a 2-D slab test:
