@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds-sweep", action="store_true", help="skip the secondary measurement of the LDS sweep kernel")
     ap.add_argument("--cpu-sample", default="240x135x1", help="WxHxSPP sample of the same scene for the CPU leg")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the gather goes through gloo on host "
+                         "copies (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
     return ap.parse_args()
 
 
@@ -154,11 +157,16 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import rust_raytracing_amd as rtx
     from rust_raytracing_amd import scenes, tiles
@@ -168,14 +176,18 @@ def main():
     objs = scenes.random_spheres(N_SPHERES, 1)
     cfg = rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=args.kernel)
     scene = rtx.Scene.from_packed(cfg, rtx.Camera(*scenes.CAMERA), objs)
-    handle = scene.upload(local_rank)                          # scene resident in HBM before the timed region
+    handle = scene.upload(dev_index)                           # scene resident in HBM before the timed region
     rb, rs, n_rows = tiles.rows_for_rank(HEIGHT, rank, world)
     band = tiles.alloc_band(HEIGHT, WIDTH, world, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         st = handle.render_rows(WIDTH, HEIGHT, rb, rs, n_rows, band.data_ptr(), stream=stream)
-        full = tiles.gather_bands(band, HEIGHT, WIDTH, rank, world, dst=0)
+        if rehearse:
+            torch.cuda.synchronize(dev)
+            full = tiles.gather_bands(band.cpu(), HEIGHT, WIDTH, rank, world, dst=0)
+        else:
+            full = tiles.gather_bands(band, HEIGHT, WIDTH, rank, world, dst=0)
         return st, full
 
     def fence():
@@ -197,7 +209,7 @@ def main():
 
     elapsed, acc, full = timed(args.warmup, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed, float(acc.segments)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(acc.segments)], dtype=torch.float64, device="cpu" if rehearse else dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -224,6 +236,7 @@ def main():
             "metric": "Mrays/s (primary rays, whole node), 10k-sphere 1080p 64spp",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            **({"rehearsal": "all ranks on cuda:0, gloo gather through host memory: not a measurement"} if rehearse else {}),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: 10k random spheres (scene seed 1), 1920x1080, %d spp per GPU (%d total), "
                                    "max_bounces 10, render seed 42" % (spp_per_gpu, spp),

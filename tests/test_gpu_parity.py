@@ -624,3 +624,26 @@ def test_bench_line_contract(gpu):
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
     assert d["lds_sweep"]["image_identical_to_value_kernel"] is True
 
+
+def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
+    """The N = 2 path of bench.py with both ranks on this box's one GPU (gloo gather through host copies, because RCCL
+    refuses two ranks on one device): launch line, row partition, per-rank render, gather, de-interleave, max-over-ranks
+    timing -- and the assembled 2 x 2 spp frame has the mean of a single-rank 4 spp frame (same pixels, same samples)."""
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "1", "--warmup", "0", "--spp", "2", "--no-cpu-baseline", "--no-lds-sweep"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + common,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["rays_per_pixel"] == 4 and "rehearsal" in d2
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--spp", "4",
+                          "--no-cpu-baseline", "--no-lds-sweep"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    # (the means are reduced on different devices -- host copy vs GPU tensor -- so they may differ in the last bits)
+    assert abs(d1["image_mean"] - d2["image_mean"]) <= 1e-12 and d1["segments_per_primary_ray"] == d2["segments_per_primary_ray"]
+
