@@ -174,6 +174,15 @@ int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t 
  * device's / and sqrt are correctly rounded and to measure how far its sin/cos are from libm. */
 int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n);
 
+/* Test hook, needs no GPU: runs the host half of rtx_scene_upload (scene packing, filter records, the SAH build of
+ * the flat BVH -- SURVEY 8f row N2; the reference's analogue is gpu_state.rs:53-77) and checks the tree's
+ * invariants: every child box inside its parent's, every sphere / triangle-footprint inside its leaf's box, every
+ * shape of the tree in exactly one leaf, links and layout flags consistent, depth as recorded.  stats[16]:
+ * 0 spheres, 1 triangles, 2 triangle filter records, 3 of them in the tree, 4 wide nodes, 5 depth, 6 binary nodes,
+ * 7 flags (1 spheres in the tree, 2 triangles in the tree), 8 sphere leaf entries seen, 9 triangle leaf entries seen,
+ * 10 largest leaf, 11 flat (footprint) nodes, 12 stack entries bound (3*depth+2), 13..15 reserved. */
+int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ from .abi import (OBJECT_DTYPE, RTX_KERNEL_AUTO, RTX_KERNEL_BVH, RTX_KERNEL_EXAC
 
 __all__ = ["Vector3", "Material", "Sphere", "Plane", "Triangle", "Object", "Config", "Camera", "Scene",
            "SceneHandle", "RtxError", "device_count", "pack_objects", "OBJECT_DTYPE",
-           "RTX_KERNEL_AUTO", "RTX_KERNEL_EXACT", "RTX_KERNEL_MIXED", "RTX_KERNEL_MIXED_VERIFY", "RTX_KERNEL_BVH", "RTX_KERNEL_BVH_REGROUP"]
+           "RTX_KERNEL_AUTO", "RTX_KERNEL_EXACT", "RTX_KERNEL_MIXED", "RTX_KERNEL_MIXED_VERIFY", "RTX_KERNEL_BVH", "RTX_KERNEL_BVH_REGROUP", "debug_host_scene"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -358,6 +358,21 @@ class SceneHandle:
             self.close()
         except Exception:
             pass
+
+
+HOST_SCENE_STATS = ("spheres", "triangles", "tri_filter_records", "tri_in_tree", "wide_nodes", "depth", "binary_nodes", "flags",
+                    "sphere_leaf_entries", "tri_leaf_entries", "largest_leaf", "flat_nodes", "stack_bound")
+
+
+def debug_host_scene(scene):
+    """Host half of the upload (packing, filter records, SAH build of the flat BVH) + a check of the tree's invariants;
+    needs no GPU.  Returns the statistics as a dict; raises RtxError when an invariant is violated."""
+    import ctypes as C
+    packed = scene.packed()
+    sc = _scene_c(scene.config, scene.camera, packed)
+    stats = (C.c_uint64 * 16)()
+    abi.check(load_library().rtx_debug_host_scene(C.byref(sc), stats))
+    return dict(zip(HOST_SCENE_STATS, (int(v) for v in stats)))
 
 
 def debug_math(op, a, b=None):

@@ -156,72 +156,26 @@ void free_handle(RtxSceneHandle_ *h)
 
 }  // namespace
 
-extern "C" {
-
-int32_t rtx_version(void) { return RTX_HIP_VERSION; }
-
-const char *rtx_last_error(void) { return g_last_error.c_str(); }
-
-int32_t rtx_device_count(void) { return usable_device_count(); }
-
-int32_t rtx_camera_new(const double position[3], const double direction[3], double fov, RtxCamera *out)
-{
-    if (!position || !direction || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_camera_new: null argument");
-    // camera.rs:42-49 derive_to_world_space_mat
-    V3 cam_forward = vnorm(mk(direction[0], direction[1], direction[2]));
-    V3 cam_right = cross(cam_forward, mk(0., 0., -1.));
-    V3 cam_up = cross(cam_forward, cam_right);
-    // Mat3x3::new(right, up, forward).transpose()  (specific_math.rs:16-21)
-    V3 rx = mk(cam_right.x, cam_up.x, cam_forward.x);
-    V3 ry = mk(cam_right.y, cam_up.y, cam_forward.y);
-    V3 rz = mk(cam_right.z, cam_up.z, cam_forward.z);
-    // inverse = adjugate / determinant  (specific_math.rs:10-14, :23-71; mat/div.rs:10-20)
-    double a = rx.x, b = rx.y, c = rx.z, d = ry.x, e = ry.y, f = ry.z, g = rz.x, hh = rz.y, i = rz.z;
-    double sum1 = a * e * i, sum2 = b * f * g, sum3 = c * d * hh;
-    double sub1 = g * e * c, sub2 = hh * f * a, sub3 = i * d * b;
-    double det = (sum1 + sum2 + sum3) - (sub1 + sub2 + sub3);
-    V3 ax = mk(e * i - f * hh, c * hh - b * i, b * f - c * e);
-    V3 ay = mk(f * g - d * i, a * i - c * g, c * d - a * f);
-    V3 az = mk(d * hh - e * g, b * g - a * hh, a * e - b * d);
-    V3 ix = vdivs(ax, det), iy = vdivs(ay, det), iz = vdivs(az, det);
-    out->fov = fov;
-    for (int k = 0; k < 3; ++k) { out->position[k] = position[k]; out->direction[k] = direction[k]; }
-    const V3 w[3] = { rx, ry, rz }, cinv[3] = { ix, iy, iz };
-    for (int r = 0; r < 3; ++r) {
-        out->to_world_space[3 * r] = w[r].x; out->to_world_space[3 * r + 1] = w[r].y; out->to_world_space[3 * r + 2] = w[r].z;
-        out->to_cam_space[3 * r] = cinv[r].x; out->to_cam_space[3 * r + 1] = cinv[r].y; out->to_cam_space[3 * r + 2] = cinv[r].z;
-    }
-    return RTX_OK;
-}
-
-int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *out)
-{
-    if (!scene || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: null argument");
-    *out = nullptr;
-    if (scene->n_objects && !scene->objects) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: objects is null");
-    if (scene->n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: too many objects");
-    if (int32_t rc = check_config(scene->config)) return rc;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
-        (void)hipGetLastError();
-        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; librtx_hip has no CPU fallback");
-    }
-    if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: bad device index");
-    if (!device_is_gfx950(device)) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library targets gfx950 only");
-    RTX_HIP_CHECK(hipSetDevice(device));
-
-    RtxSceneHandle_ *h = new RtxSceneHandle_();
-    h->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, "hipGetDeviceProperties failed"); }
-    h->n_cus = prop.multiProcessorCount;
-    h->cam = scene->camera;
-    apply_config(h, scene->config);
-
-    const uint64_t n = scene->n_objects;
+// Everything rtx_scene_upload prepares on the host: per-type shape arrays with scene-order ids, the ray-independent
+// precompute, the f32 filter records and the BVH.  No HIP call in here (rtx_debug_host_scene runs it without a GPU).
+struct PackedScene {
+    SceneView sv{};
     std::vector<SphereX> spheres; std::vector<uint32_t> sphere_id;
     std::vector<PlaneX> planes; std::vector<TriX> tris;
-    std::vector<MaterialX> mats(n);
+    std::vector<MaterialX> mats;
+    std::vector<float4> sph32, tri32, leaf32;
+    std::vector<uint32_t> tri_fidx;
+    BvhBuild bvh;
+    Bvh4Build bvh4;
+};
+
+int32_t pack_scene(const RtxScene *scene, PackedScene &p)
+{
+    const uint64_t n = scene->n_objects;
+    std::vector<SphereX> &spheres = p.spheres; std::vector<uint32_t> &sphere_id = p.sphere_id;
+    std::vector<PlaneX> &planes = p.planes; std::vector<TriX> &tris = p.tris;
+    std::vector<MaterialX> &mats = p.mats;
+    mats.assign(n, MaterialX());
     double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (uint64_t k = 0; k < n; ++k) {
         const RtxObject &o = scene->objects[k];
@@ -243,7 +197,6 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
                     if (std::isfinite(o.geom[c])) { lo[c % 3] = std::fmin(lo[c % 3], o.geom[c]); hi[c % 3] = std::fmax(hi[c % 3], o.geom[c]); }
                 break;
             default:
-                free_handle(h);
                 return fail(RTX_ERR_UNSUPPORTED, "object " + std::to_string(k) + ": kind " + std::to_string(o.kind) +
                                                      " has no device primitive (user CustomShape impls cannot run on the GPU)");
         }
@@ -252,7 +205,8 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     // v_pk_fma_f32: record 2k = {x[2k], x[2k+1], y[2k], y[2k+1]}, record 2k+1 = {z.., w..}, w = |c|^2 - r^2;
     // padded to a multiple of 4 spheres with a sentinel that never passes (w = 1e30)
     const size_t ns4 = (spheres.size() + 3) & ~(size_t)3;
-    std::vector<float4> sph32(ns4);
+    std::vector<float4> &sph32 = p.sph32;
+    sph32.assign(ns4, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<float> fx(ns4, 0.f), fy(ns4, 0.f), fz(ns4, 0.f), fw(ns4, 1.0e30f);
     double centre[3] = { 0, 0, 0 };
     for (int c = 0; c < 3; ++c) if (lo[c] <= hi[c]) centre[c] = 0.5 * (lo[c] + hi[c]);
@@ -325,51 +279,136 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
         spheres_finite = sphere_box(scene->objects[sphere_id[k]].geom, sphere_boxes[k]);
     if (!spheres_finite) sphere_boxes.clear();
     static const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
-    BvhBuild bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(), use_sah);
-    Bvh4Build bvh4 = collapse_to_bvh4(bvh);
+    BvhBuild &bvh = p.bvh;
+    bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(), use_sah);
+    Bvh4Build &bvh4 = p.bvh4;
+    bvh4 = collapse_to_bvh4(bvh);
 
     // records in leaf order first (a triangle leaf's link indexes them), then the always-candidates
-    std::vector<float4> tri32;
-    std::vector<uint32_t> tri_fidx;
+    std::vector<float4> &tri32 = p.tri32;
+    std::vector<uint32_t> &tri_fidx = p.tri_fidx;
     tri32.reserve(2 * (plain_recs.size() + always_recs.size()));
     if (bvh.has_tris) {
         for (uint32_t idx : bvh.tri_order) { const TriRec &r = plain_recs[idx]; tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
     } else {
         for (const TriRec &r : plain_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
     }
-    h->sv.n_tri_tree = bvh.has_tris ? (uint32_t)plain_recs.size() : 0u;
+    p.sv.n_tri_tree = bvh.has_tris ? (uint32_t)plain_recs.size() : 0u;
     for (const TriRec &r : always_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
     if (!tri32.empty()) {                       // one pad record: bvh_step reads records in pairs
         tri32.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
         tri32.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    h->sv.n_tri_filter = (uint32_t)tri_fidx.size();
-    h->sv.tri_extent = tri_extent;
-    h->sv.n_objects = (uint32_t)n;
-    h->sv.n_spheres = (uint32_t)spheres.size();
-    h->sv.n_planes = (uint32_t)planes.size();
-    h->sv.n_tris = (uint32_t)tris.size();
-    for (int c = 0; c < 3; ++c) h->sv.sphere_center[c] = centre[c];
-    h->sv.sphere_cmax = cmax;
-    h->sv.cam_pos = mk(h->cam.position[0], h->cam.position[1], h->cam.position[2]);
-    h->sv.to_world_x = mk(h->cam.to_world_space[0], h->cam.to_world_space[1], h->cam.to_world_space[2]);
-    h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
-    h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
+    p.sv.n_tri_filter = (uint32_t)tri_fidx.size();
+    p.sv.tri_extent = tri_extent;
+    p.sv.n_objects = (uint32_t)n;
+    p.sv.n_spheres = (uint32_t)spheres.size();
+    p.sv.n_planes = (uint32_t)planes.size();
+    p.sv.n_tris = (uint32_t)tris.size();
+    for (int c = 0; c < 3; ++c) p.sv.sphere_center[c] = centre[c];
+    p.sv.sphere_cmax = cmax;
 
-    h->sv.n_bvh_nodes = (uint32_t)bvh4.nodes.size();
-    h->sv.bvh_depth = (uint32_t)bvh4.depth;
-    h->sv.bvh_root = bvh4.root;
-    h->sv.bvh_origin_limit = (float)bvh.origin_limit;
-    h->sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
-    h->sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);
+    p.sv.n_bvh_nodes = (uint32_t)bvh4.nodes.size();
+    p.sv.bvh_depth = (uint32_t)bvh4.depth;
+    p.sv.bvh_root = bvh4.root;
+    p.sv.bvh_origin_limit = (float)bvh.origin_limit;
+    p.sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
+    p.sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);
     if (std::getenv("RTX_HIP_DEBUG"))
         std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree, %zu always tested), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
                      spheres.size(), tris.size(), plain_recs.size(), always_recs.size(), bvh.nodes.size(), bvh4.nodes.size(), bvh4.depth);
-    std::vector<float4> leaf32(bvh.prims.size());
+    std::vector<float4> &leaf32 = p.leaf32;
+    leaf32.assign(bvh.prims.size(), make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t k = 0; k < bvh.prims.size(); ++k) {
         const uint32_t p = bvh.prims[k];
         leaf32[k] = make_float4(fx[p], fy[p], fz[p], fw[p]);
     }
+
+    return RTX_OK;
+}
+
+extern "C" {
+
+int32_t rtx_version(void) { return RTX_HIP_VERSION; }
+
+const char *rtx_last_error(void) { return g_last_error.c_str(); }
+
+int32_t rtx_device_count(void) { return usable_device_count(); }
+
+int32_t rtx_camera_new(const double position[3], const double direction[3], double fov, RtxCamera *out)
+{
+    if (!position || !direction || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_camera_new: null argument");
+    // camera.rs:42-49 derive_to_world_space_mat
+    V3 cam_forward = vnorm(mk(direction[0], direction[1], direction[2]));
+    V3 cam_right = cross(cam_forward, mk(0., 0., -1.));
+    V3 cam_up = cross(cam_forward, cam_right);
+    // Mat3x3::new(right, up, forward).transpose()  (specific_math.rs:16-21)
+    V3 rx = mk(cam_right.x, cam_up.x, cam_forward.x);
+    V3 ry = mk(cam_right.y, cam_up.y, cam_forward.y);
+    V3 rz = mk(cam_right.z, cam_up.z, cam_forward.z);
+    // inverse = adjugate / determinant  (specific_math.rs:10-14, :23-71; mat/div.rs:10-20)
+    double a = rx.x, b = rx.y, c = rx.z, d = ry.x, e = ry.y, f = ry.z, g = rz.x, hh = rz.y, i = rz.z;
+    double sum1 = a * e * i, sum2 = b * f * g, sum3 = c * d * hh;
+    double sub1 = g * e * c, sub2 = hh * f * a, sub3 = i * d * b;
+    double det = (sum1 + sum2 + sum3) - (sub1 + sub2 + sub3);
+    V3 ax = mk(e * i - f * hh, c * hh - b * i, b * f - c * e);
+    V3 ay = mk(f * g - d * i, a * i - c * g, c * d - a * f);
+    V3 az = mk(d * hh - e * g, b * g - a * hh, a * e - b * d);
+    V3 ix = vdivs(ax, det), iy = vdivs(ay, det), iz = vdivs(az, det);
+    out->fov = fov;
+    for (int k = 0; k < 3; ++k) { out->position[k] = position[k]; out->direction[k] = direction[k]; }
+    const V3 w[3] = { rx, ry, rz }, cinv[3] = { ix, iy, iz };
+    for (int r = 0; r < 3; ++r) {
+        out->to_world_space[3 * r] = w[r].x; out->to_world_space[3 * r + 1] = w[r].y; out->to_world_space[3 * r + 2] = w[r].z;
+        out->to_cam_space[3 * r] = cinv[r].x; out->to_cam_space[3 * r + 1] = cinv[r].y; out->to_cam_space[3 * r + 2] = cinv[r].z;
+    }
+    return RTX_OK;
+}
+
+int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *out)
+{
+    if (!scene || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: null argument");
+    *out = nullptr;
+    if (scene->n_objects && !scene->objects) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: objects is null");
+    if (scene->n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: too many objects");
+    if (int32_t rc = check_config(scene->config)) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        (void)hipGetLastError();
+        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; librtx_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: bad device index");
+    if (!device_is_gfx950(device)) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library targets gfx950 only");
+    RTX_HIP_CHECK(hipSetDevice(device));
+
+    RtxSceneHandle_ *h = new RtxSceneHandle_();
+    h->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, "hipGetDeviceProperties failed"); }
+    h->n_cus = prop.multiProcessorCount;
+    h->cam = scene->camera;
+    apply_config(h, scene->config);
+
+    PackedScene p;
+    if (int32_t prc = pack_scene(scene, p)) { free_handle(h); return prc; }
+    {   // keep what apply_config / the camera put into h->sv, take the rest from the packed scene
+        SceneView sv = p.sv;
+        sv.rays_per_pixel = h->sv.rays_per_pixel; sv.max_bounces = h->sv.max_bounces;
+        sv.focal_length = h->sv.focal_length; sv.focal_offset = h->sv.focal_offset; sv.non_focal_offset = h->sv.non_focal_offset;
+        sv.seed = h->sv.seed;
+        h->sv = sv;
+    }
+    h->sv.cam_pos = mk(h->cam.position[0], h->cam.position[1], h->cam.position[2]);
+    h->sv.to_world_x = mk(h->cam.to_world_space[0], h->cam.to_world_space[1], h->cam.to_world_space[2]);
+    h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
+    h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
+    const std::vector<SphereX> &spheres = p.spheres; const std::vector<uint32_t> &sphere_id = p.sphere_id;
+    const std::vector<PlaneX> &planes = p.planes; const std::vector<TriX> &tris = p.tris;
+    const std::vector<MaterialX> &mats = p.mats;
+    const std::vector<float4> &sph32 = p.sph32, &tri32 = p.tri32, &leaf32 = p.leaf32;
+    const std::vector<uint32_t> &tri_fidx = p.tri_fidx;
+    const BvhBuild &bvh = p.bvh;
+    const Bvh4Build &bvh4 = p.bvh4;
 
     int32_t rc = RTX_OK;
     if (!rc) rc = upload_vec(h, bvh4.nodes, &h->sv.bvh_nodes);
@@ -646,6 +685,94 @@ int32_t rtx_render(const RtxScene *scene, uint32_t width, uint32_t height, doubl
 int32_t rtx_render_to_image(const RtxScene *scene, uint32_t width, uint32_t height, uint8_t *out_rgb8)
 {
     return render_common(scene, width, height, nullptr, out_rgb8);
+}
+
+int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
+{
+    if (!scene || !stats) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_host_scene: null argument");
+    if (scene->n_objects && !scene->objects) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_host_scene: objects is null");
+    PackedScene p;
+    if (int32_t rc = pack_scene(scene, p)) return rc;
+    for (int k = 0; k < 16; ++k) stats[k] = 0;
+    stats[0] = p.spheres.size(); stats[1] = p.tris.size(); stats[2] = p.sv.n_tri_filter; stats[3] = p.sv.n_tri_tree;
+    stats[4] = p.bvh4.nodes.size(); stats[5] = (uint64_t)p.bvh4.depth; stats[6] = p.bvh.nodes.size(); stats[7] = p.sv.bvh_flags;
+    stats[12] = 3ull * (uint64_t)p.bvh4.depth + 2ull;
+    if (p.bvh4.nodes.empty()) return RTX_OK;
+
+    struct Box { float lo[3], hi[3]; };
+    auto inside = [](const Box &c, const Box &o) {
+        for (int a = 0; a < 3; ++a) if (!(c.lo[a] >= o.lo[a] && c.hi[a] <= o.hi[a])) return false;
+        return true;
+    };
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    const size_t n_nodes = p.bvh4.nodes.size();
+    std::vector<uint8_t> node_seen(n_nodes, 0), sphere_seen(p.spheres.size(), 0), tri_seen(p.sv.n_tri_tree, 0);
+    struct Item { uint32_t link; Box box; int depth; };
+    std::vector<Item> todo;
+    Box all;
+    for (int a = 0; a < 3; ++a) { all.lo[a] = -INFINITY; all.hi[a] = INFINITY; }
+    todo.push_back({p.bvh4.root, all, 1});
+    int depth = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        const uint32_t idx = it.link & ~kBvhFlatNode;
+        const bool flat = (it.link & kBvhFlatNode) != 0u;
+        if (idx >= n_nodes) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: link out of range");
+        if (node_seen[idx]++) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: node reached twice");
+        depth = std::max(depth, it.depth);
+        if (flat) stats[11] += 1;
+        const Bvh4Node &w = p.bvh4.nodes[idx];
+        for (int c = 0; c < 4; ++c) {
+            Box b;
+            uint32_t link, count;
+            if (flat) {
+                const float lk[4] = { w.b[0].x, w.b[0].y, w.b[0].z, w.b[0].w }, ct[4] = { w.b[1].x, w.b[1].y, w.b[1].z, w.b[1].w };
+                b.lo[0] = w.a[c].x; b.lo[1] = w.a[c].y; b.hi[0] = w.a[c].z; b.hi[1] = w.a[c].w; b.lo[2] = -INFINITY; b.hi[2] = INFINITY;
+                link = bits(lk[c]); count = bits(ct[c]);
+            } else {
+                b.lo[0] = w.a[c].x; b.lo[1] = w.a[c].y; b.lo[2] = w.a[c].z; b.hi[0] = w.b[c].x; b.hi[1] = w.b[c].y; b.hi[2] = w.b[c].z;
+                link = bits(w.a[c].w); count = bits(w.b[c].w);
+            }
+            if (count == 0xFFFFFFFFu) continue;                                   // empty slot
+            if (!inside(b, it.box)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: child box outside its parent's");
+            if (count == 0u) { todo.push_back({link, b, it.depth + 1}); continue; }
+            const uint32_t n = count & 0xFFFFu;
+            stats[10] = std::max<uint64_t>(stats[10], n);
+            if (count & kBvhTriLeaf) {
+                if (!flat && !(std::isinf(b.lo[2]) && std::isinf(b.hi[2]))) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle leaf with a bounded z slab");
+                for (uint32_t k = 0; k < n; ++k) {
+                    const uint32_t rec = link + k;
+                    if (rec >= p.sv.n_tri_tree) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle record out of range");
+                    if (tri_seen[rec]++) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle in two leaves");
+                    const RtxObject &o = scene->objects[p.tris[p.tri_fidx[rec]].id];
+                    BvhBox fp;
+                    if (!triangle_footprint(o.geom, fp)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: non-finite triangle in the tree");
+                    for (int a = 0; a < 2; ++a)
+                        if (!((double)b.lo[a] <= fp.lo[a] && (double)b.hi[a] >= fp.hi[a]))
+                            return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: footprint outside its leaf");
+                    stats[9] += 1;
+                }
+            } else {
+                for (uint32_t k = 0; k < n; ++k) {
+                    if (link + k >= p.bvh.prims.size()) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: sphere entry out of range");
+                    const uint32_t sidx = p.bvh.prims[link + k];
+                    if (sidx >= p.spheres.size() || sphere_seen[sidx]++) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: sphere in two leaves");
+                    BvhBox sb;
+                    if (!sphere_box(scene->objects[p.sphere_id[sidx]].geom, sb)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: non-finite sphere in the tree");
+                    for (int a = 0; a < 3; ++a)
+                        if (!((double)b.lo[a] <= sb.lo[a] && (double)b.hi[a] >= sb.hi[a]))
+                            return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: sphere outside its leaf");
+                    stats[8] += 1;
+                }
+            }
+        }
+    }
+    if (depth != p.bvh4.depth) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: recorded depth differs");
+    for (size_t k = 0; k < n_nodes; ++k) if (!node_seen[k]) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: unreachable node");
+    if ((p.sv.bvh_flags & 1u) && stats[8] != p.spheres.size()) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: a sphere is in no leaf");
+    if ((p.sv.bvh_flags & 2u) && stats[9] != p.sv.n_tri_tree) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: a triangle is in no leaf");
+    return RTX_OK;
 }
 
 int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n)

@@ -164,3 +164,54 @@ def test_scene_generators_are_deterministic():
     assert t.tobytes() == scenes.random_triangles(1000, 2).tobytes()
     # the arrays BASELINE.json's configs are built from, pinned by hash
     assert hashlib.sha256(a.tobytes()).hexdigest()[:16] == open(os.path.join(ROOT, "tests", "golden", "scene_hashes.txt")).read().split()[1]
+
+
+# ---- host half of the upload: scene packing + SAH build of the flat BVH, checked without a GPU ----
+def _host_scene(rtx, objs):
+    from rust_raytracing_amd import scenes
+    return rtx.debug_host_scene(rtx.Scene.from_packed(rtx.Config(), rtx.Camera(*scenes.CAMERA), objs))
+
+
+def test_bvh_invariants_on_the_benchmark_scenes(rtx):
+    """rtx_debug_host_scene builds what rtx_scene_upload builds and walks the tree: child boxes inside their parents', every
+    sphere / footprint inside its leaf's box, every shape in exactly one leaf, links, layout flags and depth consistent."""
+    from rust_raytracing_amd import scenes
+    st = _host_scene(rtx, scenes.random_spheres(10000, 1))                       # C2
+    assert st["flags"] == 1 and st["sphere_leaf_entries"] == 10000 and st["largest_leaf"] == 1 and st["flat_nodes"] == 0
+    assert st["depth"] <= 9 and st["stack_bound"] <= 30                          # C2 runs the LDS-stack-only kernel variant
+    st = _host_scene(rtx, scenes.random_triangles(100000, 2))                    # C3
+    assert st["flags"] == 2 and st["tri_in_tree"] == st["tri_leaf_entries"] == st["tri_filter_records"]
+    assert 45000 < st["tri_in_tree"] < 56000                                     # about half are culled for every direction (SURVEY H2a)
+    assert st["flat_nodes"] == st["wide_nodes"] and st["largest_leaf"] == 2
+    st = _host_scene(rtx, scenes.mixed_scene(60, 50, 2, seed=21))                # joint root: spheres + triangles
+    assert st["flags"] == 3 and st["sphere_leaf_entries"] == 60 and 0 < st["flat_nodes"] < st["wide_nodes"]
+    st = _host_scene(rtx, scenes.three_spheres())                                # C1: too small for a tree
+    assert st["wide_nodes"] == 0 and st["flags"] == 0
+
+
+def test_bvh_invariants_on_awkward_and_random_scenes(rtx):
+    from helpers import fuzz_scene
+    from rust_raytracing_amd import scenes
+    o = scenes.compact(scenes.random_spheres(64, 9))
+    o["geom"][5:60:2] = (5.0, 0.0, 0.0, 1.5, 0, 0, 0, 0, 0)                      # many identical spheres: zero-extent centroid bounds
+    assert _host_scene(rtx, o)["sphere_leaf_entries"] == 64
+    o = scenes.random_spheres(100, 3)
+    o[7]["geom"][0] = float("nan")                                                # a non-finite sphere: no sphere sub-tree
+    assert _host_scene(rtx, o)["flags"] == 0
+    o = scenes.random_triangles(300, 4)
+    o["geom"] *= 1.0e29                                                           # beyond the f32 slab test's range: no tree at all
+    assert _host_scene(rtx, o)["wide_nodes"] == 0
+    o = scenes.random_triangles(64, 5)
+    o["geom"][:, 3:6] = o["geom"][:, 0:3]                                         # all degenerate: nothing can be hit, nothing in the tree
+    assert _host_scene(rtx, o)["tri_filter_records"] == 0
+    rng = np.random.default_rng(7)
+    built = 0
+    for _ in range(200):
+        objs, _cam = fuzz_scene(rtx, rng)
+        st = _host_scene(rtx, objs)                                               # raises on any violated invariant
+        built += st["wide_nodes"] > 0
+        assert st["tri_leaf_entries"] == st["tri_in_tree"] or not (st["flags"] & 2)
+    assert built > 100
+    deep = _host_scene(rtx, scenes.random_triangles(600000, 2))                   # deep enough for the HBM stack spill variant
+    assert deep["stack_bound"] > 30 and deep["tri_leaf_entries"] == deep["tri_in_tree"]
+
