@@ -16,6 +16,11 @@
  * All entry points return 0 on success; on failure they return a non-zero RtxStatus and
  * rtx_last_error() (thread-local) describes the failure.  There is NO CPU fallback: without
  * a usable gfx950 device every render entry point fails with RTX_ERR_NO_DEVICE.
+ *
+ * Threads: Scene::render(&self) is re-entrant in the reference (clones share the shapes behind Arc<Mutex>,
+ * object.rs:9-15); here rtx_render / rtx_render_to_image may be called from any number of threads at once (each call
+ * owns its device buffers; the library keeps no global mutable state besides the thread-local error string).  An
+ * RtxSceneHandle owns scratch memory and is for one thread at a time; upload one handle per rendering thread or rank.
  */
 #ifndef RTX_HIP_H
 #define RTX_HIP_H
