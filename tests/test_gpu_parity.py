@@ -420,6 +420,36 @@ def test_edge_scenes_match_oracle(gpu, oracle, name):
         assert max_abs_diff(img, ref) <= ATOL * scale, (name, kern)
 
 
+def test_render_is_reentrant_across_threads(gpu, oracle):
+    """Scene::render(&self) may be called from several threads at once in the reference (scene.rs:144; shapes shared behind
+    Arc<Mutex>, object.rs:9-15).  Six threads render different scenes / kernels through rtx_render concurrently (ctypes drops
+    the GIL for the call); every frame must equal its oracle frame."""
+    import threading
+    from rust_raytracing_amd import scenes
+    jobs = [(scenes.three_spheres(), gpu.RTX_KERNEL_AUTO), (scenes.mixed_scene(60, 50, 2, seed=21), gpu.RTX_KERNEL_BVH),
+            (scenes.compact(scenes.random_spheres(500, 3), k=0.3), gpu.RTX_KERNEL_MIXED),
+            (scenes.light_every(scenes.compact(scenes.random_triangles(400, 5)), 3), gpu.RTX_KERNEL_BVH_REGROUP),
+            (scenes.mixed_scene(30, 80, 1, seed=5), gpu.RTX_KERNEL_EXACT), (scenes.compact(scenes.random_spheres(900, 8), k=0.3), gpu.RTX_KERNEL_AUTO)]
+    refs = [oracle_render(oracle, o, 48, 30, rays_per_pixel=3, seed=9) for o, _ in jobs]
+    out, errs = [None] * len(jobs), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = hip_render(gpu, jobs[i][0], 48, 30, kernel=jobs[i][1], rays_per_pixel=3, seed=9)
+        except Exception as e:          # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i, ref in enumerate(refs):
+        assert max_abs_diff(out[i], ref) <= ATOL, i
+
+
 def test_unsupported_and_invalid_arguments(gpu):
     from rust_raytracing_amd import scenes
     bad = scenes.three_spheres().copy()
