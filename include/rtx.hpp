@@ -291,6 +291,13 @@ public:
         c.seed = config.seed; c.kernel = config.kernel;
         check(rtx_scene_set_config(h_, &c));
     }
+    void add_object(const object::Object &o)                           // Scene::add_object, scene.rs:126-128
+    {
+        Scene one;
+        one.add_object(o);
+        const std::vector<RtxObject> packed = one.pack();
+        check(rtx_scene_append_objects(h_, packed.data(), packed.size()));
+    }
     // rows row_begin, row_begin + row_stride, ... (n_rows of them) of the width x height image -> d_out_rgb[n_rows][width][3]
     RtxStats render_rows(std::size_t width, std::size_t height, std::size_t row_begin, std::size_t row_stride, std::size_t n_rows,
                          double *d_out_rgb, void *hip_stream = nullptr)

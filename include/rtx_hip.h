@@ -151,6 +151,12 @@ int32_t rtx_scene_free(RtxSceneHandle scene);
 /* Replace the Config of an uploaded scene (rays_per_pixel, seed, kernel, ...). */
 int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config);
 
+/* Scene::add_object (scene.rs:126-128) on an uploaded scene: the objects are appended in order (they get the next scene
+ * indices, so earlier objects still win ties, scene.rs:250), the shape arrays, filter records and the BVH are rebuilt on
+ * the host and replace the resident ones; config, camera and scratch stay.  Waits for renders in flight on the handle's
+ * device.  On failure (e.g. an unsupported kind) the resident scene is unchanged. */
+int32_t rtx_scene_append_objects(RtxSceneHandle scene, const RtxObject *objects, uint64_t n_objects);
+
 /* Replace the Camera of an uploaded scene without re-uploading the objects (the reference's analogue is
  * Scene.camera being a pub field, scene.rs:82, with Camera::set_direction camera.rs:35-40).  Only fov, position and
  * to_world_space are read by render. */

@@ -339,6 +339,12 @@ class SceneHandle:
         c = camera.to_c()
         abi.check(self._lib.rtx_scene_set_camera(self._h, C.byref(c)))
 
+    def append_objects(self, packed):
+        """Scene::add_object (scene.rs:126-128) for a resident scene: `packed` is an OBJECT_DTYPE array (or a list of Objects)."""
+        arr = packed if isinstance(packed, np.ndarray) else pack_objects(packed)
+        arr = np.ascontiguousarray(arr, dtype=OBJECT_DTYPE)
+        abi.check(self._lib.rtx_scene_append_objects(self._h, arr.ctypes.data, len(arr)))
+
     def render_rows(self, width, height, row_begin, row_stride, n_rows, d_out_ptr, stream=None, want_stats=True):
         """d_out_ptr: device address of n_rows*width*3 doubles (e.g. a torch tensor's data_ptr())."""
         stats = abi.RtxStats()

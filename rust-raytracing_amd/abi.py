@@ -57,6 +57,7 @@ SYMBOLS = [
     ("rtx_scene_free", C.c_int32, [C.c_void_p]),
     ("rtx_scene_set_config", C.c_int32, [C.c_void_p, C.POINTER(RtxConfig)]),
     ("rtx_scene_set_camera", C.c_int32, [C.c_void_p, C.POINTER(RtxCamera)]),
+    ("rtx_scene_append_objects", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("rtx_render_rows", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.POINTER(RtxStats)]),
     ("rtx_quantize_image_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),

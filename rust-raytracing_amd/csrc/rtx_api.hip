@@ -72,6 +72,7 @@ struct RtxSceneHandle_ {
     RtxConfig cfg{};
     RtxCamera cam{};
     SceneView sv{};
+    std::vector<RtxObject> objects;                       // Scene.objects as uploaded (rtx_scene_append_objects re-packs them)
     std::vector<void *> scene_allocs;
     // scratch, grown on demand
     double *samples = nullptr;  size_t samples_bytes = 0;
@@ -327,6 +328,51 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     return RTX_OK;
 }
 
+// Packs `scene`'s objects and puts them (shape arrays, filter records, BVH) on the handle's device, replacing what
+// was there.  Config and camera of the handle are kept.
+int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
+{
+    PackedScene p;
+    if (int32_t prc = pack_scene(scene, p)) return prc;
+    {   // keep what apply_config / the camera put into h->sv, take the rest from the packed scene
+        SceneView sv = p.sv;
+        sv.rays_per_pixel = h->sv.rays_per_pixel; sv.max_bounces = h->sv.max_bounces;
+        sv.focal_length = h->sv.focal_length; sv.focal_offset = h->sv.focal_offset; sv.non_focal_offset = h->sv.non_focal_offset;
+        sv.seed = h->sv.seed;
+        h->sv = sv;
+    }
+    h->sv.cam_pos = mk(h->cam.position[0], h->cam.position[1], h->cam.position[2]);
+    h->sv.to_world_x = mk(h->cam.to_world_space[0], h->cam.to_world_space[1], h->cam.to_world_space[2]);
+    h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
+    h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
+    const std::vector<SphereX> &spheres = p.spheres; const std::vector<uint32_t> &sphere_id = p.sphere_id;
+    const std::vector<PlaneX> &planes = p.planes; const std::vector<TriX> &tris = p.tris;
+    const std::vector<MaterialX> &mats = p.mats;
+    const std::vector<float4> &sph32 = p.sph32, &tri32 = p.tri32, &leaf32 = p.leaf32;
+    const std::vector<uint32_t> &tri_fidx = p.tri_fidx;
+    const BvhBuild &bvh = p.bvh;
+    const Bvh4Build &bvh4 = p.bvh4;
+
+    for (void *d : h->scene_allocs) (void)hipFree(d);
+    h->scene_allocs.clear();
+    int32_t rc = RTX_OK;
+    if (!rc) rc = upload_vec(h, bvh4.nodes, &h->sv.bvh_nodes);
+    if (!rc) rc = upload_vec(h, bvh.prims, &h->sv.bvh_prims);
+    if (!rc) rc = upload_vec(h, leaf32, &h->sv.bvh_leaf_f32);
+    if (!rc) rc = upload_vec(h, spheres, &h->sv.spheres);
+    if (!rc) rc = upload_vec(h, sphere_id, &h->sv.sphere_id);
+    if (!rc) rc = upload_vec(h, planes, &h->sv.planes);
+    if (!rc) rc = upload_vec(h, tris, &h->sv.tris);
+    if (!rc) rc = upload_vec(h, mats, &h->sv.materials);
+    if (!rc) rc = upload_vec(h, sph32, &h->sv.sphere_f32);
+    if (!rc) rc = upload_vec(h, tri32, &h->sv.tri_f32);
+    if (!rc) rc = upload_vec(h, tri_fidx, &h->sv.tri_fidx);
+    if (rc) return rc;
+    h->sv_dirty = true;
+    return RTX_OK;
+
+}
+
 extern "C" {
 
 int32_t rtx_version(void) { return RTX_HIP_VERSION; }
@@ -389,40 +435,8 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
     h->cam = scene->camera;
     apply_config(h, scene->config);
 
-    PackedScene p;
-    if (int32_t prc = pack_scene(scene, p)) { free_handle(h); return prc; }
-    {   // keep what apply_config / the camera put into h->sv, take the rest from the packed scene
-        SceneView sv = p.sv;
-        sv.rays_per_pixel = h->sv.rays_per_pixel; sv.max_bounces = h->sv.max_bounces;
-        sv.focal_length = h->sv.focal_length; sv.focal_offset = h->sv.focal_offset; sv.non_focal_offset = h->sv.non_focal_offset;
-        sv.seed = h->sv.seed;
-        h->sv = sv;
-    }
-    h->sv.cam_pos = mk(h->cam.position[0], h->cam.position[1], h->cam.position[2]);
-    h->sv.to_world_x = mk(h->cam.to_world_space[0], h->cam.to_world_space[1], h->cam.to_world_space[2]);
-    h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
-    h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
-    const std::vector<SphereX> &spheres = p.spheres; const std::vector<uint32_t> &sphere_id = p.sphere_id;
-    const std::vector<PlaneX> &planes = p.planes; const std::vector<TriX> &tris = p.tris;
-    const std::vector<MaterialX> &mats = p.mats;
-    const std::vector<float4> &sph32 = p.sph32, &tri32 = p.tri32, &leaf32 = p.leaf32;
-    const std::vector<uint32_t> &tri_fidx = p.tri_fidx;
-    const BvhBuild &bvh = p.bvh;
-    const Bvh4Build &bvh4 = p.bvh4;
-
-    int32_t rc = RTX_OK;
-    if (!rc) rc = upload_vec(h, bvh4.nodes, &h->sv.bvh_nodes);
-    if (!rc) rc = upload_vec(h, bvh.prims, &h->sv.bvh_prims);
-    if (!rc) rc = upload_vec(h, leaf32, &h->sv.bvh_leaf_f32);
-    if (!rc) rc = upload_vec(h, spheres, &h->sv.spheres);
-    if (!rc) rc = upload_vec(h, sphere_id, &h->sv.sphere_id);
-    if (!rc) rc = upload_vec(h, planes, &h->sv.planes);
-    if (!rc) rc = upload_vec(h, tris, &h->sv.tris);
-    if (!rc) rc = upload_vec(h, mats, &h->sv.materials);
-    if (!rc) rc = upload_vec(h, sph32, &h->sv.sphere_f32);
-    if (!rc) rc = upload_vec(h, tri32, &h->sv.tri_f32);
-    if (!rc) rc = upload_vec(h, tri_fidx, &h->sv.tri_fidx);
-    if (rc) { free_handle(h); return rc; }
+    if (int32_t irc = install_scene(h, scene)) { free_handle(h); return irc; }
+    h->objects.assign(scene->objects, scene->objects + scene->n_objects);
 
     hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
     if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
@@ -457,6 +471,30 @@ int32_t rtx_scene_set_camera(RtxSceneHandle scene, const RtxCamera *camera)
     scene->sv.to_world_y = mk(camera->to_world_space[3], camera->to_world_space[4], camera->to_world_space[5]);
     scene->sv.to_world_z = mk(camera->to_world_space[6], camera->to_world_space[7], camera->to_world_space[8]);
     scene->sv_dirty = true;                   // the trig tables are keyed on cam.fov and rebuilt when it changed
+    return RTX_OK;
+}
+
+int32_t rtx_scene_append_objects(RtxSceneHandle scene, const RtxObject *objects, uint64_t n_objects)
+{
+    if (!scene || (n_objects && !objects)) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_append_objects: null argument");
+    if (n_objects == 0) return RTX_OK;
+    if (scene->objects.size() + n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_append_objects: too many objects");
+    RTX_HIP_CHECK(hipSetDevice(scene->device));
+    RTX_HIP_CHECK(hipDeviceSynchronize());                  // a render may still read the arrays about to be replaced
+    std::vector<RtxObject> all = scene->objects;
+    all.insert(all.end(), objects, objects + n_objects);
+    RtxScene sc{};
+    sc.config = scene->cfg;
+    sc.camera = scene->cam;
+    sc.n_objects = all.size();
+    sc.objects = all.data();
+    // (pack first: an unsupported kind must leave the resident scene as it was)
+    {
+        PackedScene probe;
+        if (int32_t rc = pack_scene(&sc, probe)) return rc;
+    }
+    if (int32_t rc = install_scene(scene, &sc)) return rc;
+    scene->objects.swap(all);
     return RTX_OK;
 }
 

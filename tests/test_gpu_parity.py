@@ -314,6 +314,34 @@ def test_resident_scene_config_and_camera_updates(gpu, oracle):
     hnd.close()
 
 
+def test_resident_scene_append_objects(gpu, oracle):
+    """rtx_scene_append_objects = Scene::add_object on a resident scene (row N4): start with 30 spheres (a tree), append
+    triangles and a plane, then more spheres; after every step the frame equals the oracle's for the same object list.  A
+    failing append (unknown kind) leaves the scene as it was."""
+    import torch
+    from rust_raytracing_amd import scenes
+    parts = [scenes.compact(scenes.random_spheres(30, 4)), scenes.light_every(scenes.compact(scenes.random_triangles(40, 6)), 3),
+             scenes.mixed_scene(0, 0, 1), scenes.compact(scenes.random_spheres(25, 8))]
+    cfg = dict(rays_per_pixel=3, seed=17)
+    w, h = 48, 32
+    hnd = hip_scene(gpu, parts[0], **cfg).upload(0)
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    have = parts[0]
+    for k in range(len(parts)):
+        if k:
+            hnd.append_objects(parts[k])
+            have = np.concatenate([have, parts[k]])
+        hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        assert max_abs_diff(buf.cpu().numpy(), oracle_render(oracle, have, w, h, **cfg)) <= ATOL, k
+    bad = parts[0][:1].copy()
+    bad["kind"] = 9
+    with pytest.raises(gpu.RtxError):
+        hnd.append_objects(bad)
+    hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    assert max_abs_diff(buf.cpu().numpy(), oracle_render(oracle, have, w, h, **cfg)) <= ATOL
+    hnd.close()
+
+
 def test_sample_batching_keeps_the_left_fold(gpu, oracle, monkeypatch):
     """With scratch capped, samples are traced in several batches; the fold order (iter_ops.rs:4-8) must not change."""
     from rust_raytracing_amd import scenes
