@@ -143,6 +143,10 @@ def roofline_of(acc, traffic_key):
             out["traffic"] = rec["hbm_bytes_per_launch"] if rec else None
         except Exception:
             pass
+    # what the memory side actually moved (PMC, profiles/traffic.json) over this run's launch time: the "achieved HBM GB/s"
+    # of BASELINE.json's metric.  Far below `achieved`: the operands are served by LDS / L2, the kernels are VALU- and
+    # latency-bound
+    out["hbm_measured_gbs"] = out["traffic"] / (avg_ms * 1e-3) / 1e9 if out["traffic"] and avg_ms > 0 else None
     return out
 
 
