@@ -121,7 +121,10 @@ inline bool triangle_footprint(const double v[9], BvhBox &b)
 // area(L) * n(L) + area(R) * n(R).  When the SAH has nothing to offer (all centres in one bin) or the depth budget
 // is used up, the node is split at the median of its widest axis, which bounds the depth by
 // ceil(log2(n / leaf)) + kBvhSahExtraDepth + 1.
-constexpr int kBvhSahBins = 16;
+#ifndef RTX_BVH_SAH_BINS
+#define RTX_BVH_SAH_BINS 16
+#endif
+constexpr int kBvhSahBins = RTX_BVH_SAH_BINS;
 constexpr int kBvhSahExtraDepth = 6;
 
 inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t leaf_size, uint32_t leaf_flag,
