@@ -45,4 +45,7 @@ if __name__ == "__main__":
     n += run("mixed 3k spheres + 30k triangles + 2 planes",
              np.concatenate([scenes.random_spheres(3000, 11), scenes.random_triangles(30000, 12), scenes.mixed_scene(0, 0, 2)]),
              int(960 * scale), int(540 * scale), 1, K)
+    if "c5" in sys.argv[2:]:                      # 1M triangles: the exhaustive kernel needs ~10 s per camera at this size
+        n += run("C5 1M triangles", scenes.random_triangles(1000000, 3, box=2.0), int(480 * scale), int(270 * scale), 1,
+                 [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP])
     print("soak ok:", n, "segments compared bit for bit")
