@@ -334,6 +334,9 @@ int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
 {
     PackedScene p;
     if (int32_t prc = pack_scene(scene, p)) return prc;
+    const SceneView sv_before = h->sv;                    // restored if an upload fails: the handle then still holds the old scene
+    std::vector<void *> old_allocs;
+    old_allocs.swap(h->scene_allocs);
     {   // keep what apply_config / the camera put into h->sv, take the rest from the packed scene
         SceneView sv = p.sv;
         sv.rays_per_pixel = h->sv.rays_per_pixel; sv.max_bounces = h->sv.max_bounces;
@@ -353,8 +356,6 @@ int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
     const BvhBuild &bvh = p.bvh;
     const Bvh4Build &bvh4 = p.bvh4;
 
-    for (void *d : h->scene_allocs) (void)hipFree(d);
-    h->scene_allocs.clear();
     int32_t rc = RTX_OK;
     if (!rc) rc = upload_vec(h, bvh4.nodes, &h->sv.bvh_nodes);
     if (!rc) rc = upload_vec(h, bvh.prims, &h->sv.bvh_prims);
@@ -367,10 +368,15 @@ int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
     if (!rc) rc = upload_vec(h, sph32, &h->sv.sphere_f32);
     if (!rc) rc = upload_vec(h, tri32, &h->sv.tri_f32);
     if (!rc) rc = upload_vec(h, tri_fidx, &h->sv.tri_fidx);
-    if (rc) return rc;
+    if (rc) {
+        for (void *d : h->scene_allocs) (void)hipFree(d);
+        h->scene_allocs.swap(old_allocs);
+        h->sv = sv_before;
+        return rc;
+    }
+    for (void *d : old_allocs) (void)hipFree(d);
     h->sv_dirty = true;
     return RTX_OK;
-
 }
 
 extern "C" {
@@ -488,12 +494,7 @@ int32_t rtx_scene_append_objects(RtxSceneHandle scene, const RtxObject *objects,
     sc.camera = scene->cam;
     sc.n_objects = all.size();
     sc.objects = all.data();
-    // (pack first: an unsupported kind must leave the resident scene as it was)
-    {
-        PackedScene probe;
-        if (int32_t rc = pack_scene(&sc, probe)) return rc;
-    }
-    if (int32_t rc = install_scene(scene, &sc)) return rc;
+    if (int32_t rc = install_scene(scene, &sc)) return rc;      // (on failure the resident scene is as it was)
     scene->objects.swap(all);
     return RTX_OK;
 }
