@@ -196,13 +196,16 @@ public:
     Scene(Config config_, Camera camera_) : camera(std::move(camera_)), config(config_) {}   // Scene::new, scene.rs:112-118
     void add_object(object::Object o) { objects.push_back(std::move(o)); }                  // scene.rs:126-128
 
-    // Scene::render, scene.rs:144-170: img[y][x]
-    std::vector<std::vector<Vector3>> render(std::size_t width, std::size_t height) const
+    // Scene::render, scene.rs:144-170: img[y][x].  `devices`: the GPUs the frame is partitioned over (interleaved row
+    // bands, one gather on devices[0]; rtx_render_devices); empty = device 0.  The pixels do not depend on it.
+    std::vector<std::vector<Vector3>> render(std::size_t width, std::size_t height, const std::vector<int32_t> &devices = {}) const
     {
         std::vector<double> flat(width * height * 3);
         std::vector<RtxObject> packed = pack();
         RtxScene sc = to_c(packed);
-        int32_t rc = rtx_render(&sc, (uint32_t)width, (uint32_t)height, flat.data());
+        int32_t rc = devices.empty() ? rtx_render(&sc, (uint32_t)width, (uint32_t)height, flat.data())
+                                     : rtx_render_devices(&sc, (uint32_t)width, (uint32_t)height, devices.data(),
+                                                          (uint32_t)devices.size(), flat.data());
         if (rc != RTX_OK) throw Panic(rc, rtx_last_error());
         std::vector<std::vector<Vector3>> img(height, std::vector<Vector3>(width));
         for (std::size_t y = 0; y < height; ++y)
@@ -214,12 +217,14 @@ public:
     }
 
     // Scene::render_to_image, scene.rs:172-178: RGB8, row 0 = top of the image
-    std::vector<uint8_t> render_to_image(std::size_t width, std::size_t height) const
+    std::vector<uint8_t> render_to_image(std::size_t width, std::size_t height, const std::vector<int32_t> &devices = {}) const
     {
         std::vector<uint8_t> out(width * height * 3);
         std::vector<RtxObject> packed = pack();
         RtxScene sc = to_c(packed);
-        int32_t rc = rtx_render_to_image(&sc, (uint32_t)width, (uint32_t)height, out.data());
+        int32_t rc = devices.empty() ? rtx_render_to_image(&sc, (uint32_t)width, (uint32_t)height, out.data())
+                                     : rtx_render_to_image_devices(&sc, (uint32_t)width, (uint32_t)height, devices.data(),
+                                                                   (uint32_t)devices.size(), out.data());
         if (rc != RTX_OK) throw Panic(rc, rtx_last_error());
         return out;
     }

@@ -21,10 +21,15 @@
  * object.rs:9-15); here rtx_render / rtx_render_to_image may be called from any number of threads at once (each call
  * owns its device buffers; the library keeps no global mutable state besides the thread-local error string).  An
  * RtxSceneHandle owns scratch memory and is for one thread at a time; upload one handle per rendering thread or rank.
+ * Streams: a handle's device buffers are shared by all of its renders, so its work is ordered on one stream at a time --
+ * a call that brings a different stream than the previous call first waits for the previous stream to drain.
+ * With stats == NULL rtx_render_rows is asynchronous; an internal error of such a render (the sweep kernel's round-bound
+ * watchdog) is reported by the next call on the handle that finds it, at the latest by rtx_scene_free.
  */
 #ifndef RTX_HIP_H
 #define RTX_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -126,6 +131,24 @@ typedef struct RtxStats {
 
 typedef struct RtxSceneHandle_ *RtxSceneHandle;
 
+/* The layouts a binding has to reproduce (rust/src/raytracing/hip.rs: #[repr(C)]; rust-raytracing_amd/abi.py: ctypes;
+ * tests/test_abi_and_host.py checks both against these numbers). */
+#ifdef __cplusplus
+#define RTX_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define RTX_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+RTX_STATIC_ASSERT(sizeof(RtxObject) == 136 && offsetof(RtxObject, geom) == 8 && offsetof(RtxObject, base_color) == 80 &&
+                  offsetof(RtxObject, emission_color) == 104 && offsetof(RtxObject, roughness) == 128, "RtxObject layout");
+RTX_STATIC_ASSERT(sizeof(RtxConfig) == 56 && offsetof(RtxConfig, focal_length) == 16 && offsetof(RtxConfig, seed) == 40 &&
+                  offsetof(RtxConfig, kernel) == 48 && offsetof(RtxConfig, reserved) == 52, "RtxConfig layout");
+RTX_STATIC_ASSERT(sizeof(RtxCamera) == 200 && offsetof(RtxCamera, position) == 8 && offsetof(RtxCamera, direction) == 32 &&
+                  offsetof(RtxCamera, to_cam_space) == 56 && offsetof(RtxCamera, to_world_space) == 128, "RtxCamera layout");
+RTX_STATIC_ASSERT(sizeof(RtxScene) == 272 && offsetof(RtxScene, camera) == 56 && offsetof(RtxScene, n_objects) == 256 &&
+                  offsetof(RtxScene, objects) == 264, "RtxScene layout");
+RTX_STATIC_ASSERT(sizeof(RtxStats) == 72 && offsetof(RtxStats, trace_ms) == 32 && offsetof(RtxStats, box_tests) == 56 &&
+                  offsetof(RtxStats, trace_launches) == 64 && offsetof(RtxStats, kernel) == 68, "RtxStats layout");
+
 /* -- library ----------------------------------------------------------------------------- */
 int32_t     rtx_version(void);
 const char *rtx_last_error(void);
@@ -144,9 +167,22 @@ int32_t rtx_render(const RtxScene *scene, uint32_t width, uint32_t height, doubl
  * out_rgb8: height*width*3 bytes. */
 int32_t rtx_render_to_image(const RtxScene *scene, uint32_t width, uint32_t height, uint8_t *out_rgb8);
 
+/* Scene::render / render_to_image on several GPUs of one node (BASELINE north_star: "tile-partitioned across the 8 GPUs
+ * ... single gather over xGMI at the end"): still ONE call that returns the whole frame (scene.rs:144-170).  The scene is
+ * packed once and replicated; device devices[k] renders the interleaved row band y = k, k + n, ... (one host thread and
+ * one stream per device, no exchange during the render: pixels are independent, scene.rs:149-160); the bands are gathered
+ * on devices[0] with one peer copy each (hipMemcpyPeerAsync: every peer pushes over its own xGMI link; no communicator
+ * to set up), de-interleaved there and copied to the host once.  Pixel values do not depend on n_devices or the order of
+ * the list.  An entry may repeat (two bands on one device) -- that is how the path is tested on a one-GPU box.
+ * rtx_render(scene, w, h, out) == rtx_render_devices(scene, w, h, {0}, 1, out). */
+int32_t rtx_render_devices(const RtxScene *scene, uint32_t width, uint32_t height,
+                           const int32_t *devices, uint32_t n_devices, double *out_rgb);
+int32_t rtx_render_to_image_devices(const RtxScene *scene, uint32_t width, uint32_t height,
+                                    const int32_t *devices, uint32_t n_devices, uint8_t *out_rgb8);
+
 /* -- split form: upload once, render many (rows / devices), output stays on the device ------ */
 int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *out);
-int32_t rtx_scene_free(RtxSceneHandle scene);
+int32_t rtx_scene_free(RtxSceneHandle scene);      /* non-zero: an earlier asynchronous render on it had failed (see "Streams") */
 
 /* Replace the Config of an uploaded scene (rays_per_pixel, seed, kernel, ...). */
 int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config);

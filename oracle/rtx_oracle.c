@@ -611,6 +611,80 @@ int rtxo_render(const rtxo_scene *s, uint32_t width, uint32_t height,
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Selected pixels of Scene::render's width x height frame (scene.rs:144-170 restricted to a list) */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    render_ctx       ctx;
+    uint32_t         width, height;
+    double           vertical_fov;
+    uint64_t         n;
+    const uint32_t  *xs, *ys;
+    double          *out;
+    uint64_t        *segments;
+    pthread_mutex_t *cursor_lock;
+    uint64_t        *cursor;
+} pixel_job;
+
+static void *pixels_thread(void *arg)
+{
+    const pixel_job *j = (const pixel_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(j->cursor_lock);
+        uint64_t k = *j->cursor;
+        *j->cursor = k + 1;
+        pthread_mutex_unlock(j->cursor_lock);
+        if (k >= j->n)
+            return NULL;
+        uint32_t xi = j->xs[k], yi = j->ys[k];
+        double x = (double)xi / (double)j->width;                   /* scene.rs:157 */
+        double y = (double)yi / (double)j->height;                  /* scene.rs:153 */
+        uint64_t seg = 0;
+        rtxo_vec3 c = ctx_render_pixel(&j->ctx, x, y, j->vertical_fov, (uint64_t)yi * j->width + xi, j->segments ? &seg : NULL);
+        double *o = j->out + 3 * k;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        if (j->segments) j->segments[k] = seg;
+    }
+}
+
+int rtxo_render_pixels(const rtxo_scene *s, uint32_t width, uint32_t height, uint64_t n,
+                       const uint32_t *xs, const uint32_t *ys, double *out_rgb, uint64_t *segments, int n_threads)
+{
+    if (!s || (n && (!xs || !ys || !out_rgb))) return 1;
+    if (n == 0) return 0;
+    if (width == 0 || height == 0) return 1;
+    for (uint64_t k = 0; k < n; ++k)
+        if (xs[k] >= width || ys[k] >= height) return 1;
+    pixel_job job;
+    memset(&job, 0, sizeof job);
+    job.ctx.scene = s;
+    job.ctx.locks = NULL;
+    job.width = width; job.height = height;
+    job.vertical_fov = (double)height / (double)width * s->camera.fov;      /* scene.rs:145 */
+    job.n = n; job.xs = xs; job.ys = ys; job.out = out_rgb; job.segments = segments;
+    pthread_mutex_t cursor_lock = PTHREAD_MUTEX_INITIALIZER;
+    uint64_t cursor = 0;
+    job.cursor_lock = &cursor_lock;
+    job.cursor = &cursor;
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n) n_threads = (int)n;
+    if (n_threads == 1) {
+        pixels_thread(&job);
+        return 0;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    if (!th) return 2;
+    int started = 0, rc = 0;
+    for (int k = 0; k < n_threads; ++k) {
+        if (pthread_create(&th[k], NULL, pixels_thread, &job) != 0) { rc = 3; break; }
+        ++started;
+    }
+    if (started == 0) pixels_thread(&job);
+    for (int k = 0; k < started; ++k) pthread_join(th[k], NULL);
+    free(th);
+    return started ? 0 : rc;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* render_to_image (scene.rs:172-178)                                                            */
 /* ------------------------------------------------------------------------------------------- */
 static inline uint8_t rust_as_u8(double v)      /* Rust `f64 as u8`: saturating, NaN -> 0, truncation toward 0 */

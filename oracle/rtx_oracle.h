@@ -128,6 +128,16 @@ int rtxo_render(const rtxo_scene *s, uint32_t width, uint32_t height,
                 uint32_t row_begin, uint32_t row_stride,
                 double *out_rgb, uint64_t *segments, int n_threads, int mode);
 
+/*
+ * The pixels (xs[k], ys[k]), k < n, of Scene::render's width x height frame (scene.rs:144-170 restricted to a list):
+ * out_rgb[3k..3k+2] = img[ys[k]][xs[k]], segments[k] (optional) = its closest_object calls.  n_threads workers pull
+ * pixels from a shared counter (clean mode).  This is how the full-size configs (100k / 1M triangles at 1920x1080 /
+ * 3840x2160, where a whole row costs minutes) are pinned to the oracle, and how bench.py's cpu_baseline samples the
+ * benchmark's own view.  Returns 0 on success.
+ */
+int rtxo_render_pixels(const rtxo_scene *s, uint32_t width, uint32_t height, uint64_t n,
+                       const uint32_t *xs, const uint32_t *ys, double *out_rgb, uint64_t *segments, int n_threads);
+
 /* render_to_image (scene.rs:172-178): x256, saturating `as u8`, vertical flip. */
 void rtxo_quantize_image(const double *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb8);
 

@@ -114,6 +114,9 @@ def lib():
     L.rtxo_render.restype = C.c_int
     L.rtxo_render.argtypes = [C.POINTER(Scene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                               C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.rtxo_render_pixels.restype = C.c_int
+    L.rtxo_render_pixels.argtypes = [C.POINTER(Scene), C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int]
     L.rtxo_quantize_image.restype = None
     L.rtxo_quantize_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
@@ -202,6 +205,23 @@ def render(scene, width, height, n_threads=None, mode=MODE_CLEAN, row_begin=0, r
                            int(n_threads), int(mode))
     if rc != 0:
         raise RuntimeError("rtxo_render failed: %d" % rc)
+    return (out, seg) if want_segments else out
+
+
+def render_pixels(scene, width, height, xs, ys, n_threads=None, want_segments=False):
+    """img[ys[k]][xs[k]] of Scene::render's width x height frame for a list of pixels -> (n, 3) float64
+    (and (n,) uint64 closest_object counts)."""
+    if n_threads is None:
+        n_threads = os.cpu_count() or 1
+    xs = np.ascontiguousarray(xs, dtype=np.uint32)
+    ys = np.ascontiguousarray(ys, dtype=np.uint32)
+    assert xs.shape == ys.shape and xs.ndim == 1
+    out = np.zeros((len(xs), 3), dtype=np.float64)
+    seg = np.zeros(len(xs), dtype=np.uint64) if want_segments else None
+    rc = lib().rtxo_render_pixels(C.byref(scene), int(width), int(height), len(xs), xs.ctypes.data, ys.ctypes.data,
+                                  out.ctypes.data, seg.ctypes.data if want_segments else None, int(n_threads))
+    if rc != 0:
+        raise RuntimeError("rtxo_render_pixels failed: %d" % rc)
     return (out, seg) if want_segments else out
 
 

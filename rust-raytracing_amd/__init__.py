@@ -298,22 +298,31 @@ class Scene:
     def packed(self):
         return self._packed if self._packed is not None else pack_objects(self.objects)
 
-    def render(self, width, height):                                # scene.rs:144-170
-        """img[y][x] -> float64 array (height, width, 3), unclamped, row 0 = the reference's row 0."""
+    def render(self, width, height, devices=None):                  # scene.rs:144-170
+        """img[y][x] -> float64 array (height, width, 3), unclamped, row 0 = the reference's row 0.
+        devices: list of GPU indices the frame is partitioned over (rtx_render_devices); None = device 0."""
         width, height = int(width), int(height)
         out = np.zeros((height, width, 3), dtype=np.float64)
         packed = self.packed()
         sc = _scene_c(self.config, self.camera, packed)
-        abi.check(load_library().rtx_render(C.byref(sc), width, height, out.ctypes.data))
+        if devices is None:
+            abi.check(load_library().rtx_render(C.byref(sc), width, height, out.ctypes.data))
+        else:
+            dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            abi.check(load_library().rtx_render_devices(C.byref(sc), width, height, dv, len(devices), out.ctypes.data))
         return out
 
-    def render_to_image(self, width, height):                       # scene.rs:172-178
+    def render_to_image(self, width, height, devices=None):         # scene.rs:172-178
         """ImageBuffer<Rgb<u8>> as uint8 array (height, width, 3): x256, saturating, flipped vertically."""
         width, height = int(width), int(height)
         out = np.zeros((height, width, 3), dtype=np.uint8)
         packed = self.packed()
         sc = _scene_c(self.config, self.camera, packed)
-        abi.check(load_library().rtx_render_to_image(C.byref(sc), width, height, out.ctypes.data))
+        if devices is None:
+            abi.check(load_library().rtx_render_to_image(C.byref(sc), width, height, out.ctypes.data))
+        else:
+            dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            abi.check(load_library().rtx_render_to_image_devices(C.byref(sc), width, height, dv, len(devices), out.ctypes.data))
         return out
 
     def upload(self, device=0):
@@ -356,8 +365,8 @@ class SceneHandle:
 
     def close(self):
         if self._h:
-            self._lib.rtx_scene_free(self._h)
-            self._h = C.c_void_p()
+            h, self._h = self._h, C.c_void_p()
+            abi.check(self._lib.rtx_scene_free(h))      # non-zero: an earlier asynchronous render on the handle had failed
 
     def __del__(self):
         try:

@@ -53,6 +53,9 @@ SYMBOLS = [
     ("rtx_camera_new", C.c_int32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(RtxCamera)]),
     ("rtx_render", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.c_void_p]),
     ("rtx_render_to_image", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("rtx_render_devices", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p]),
+    ("rtx_render_to_image_devices", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32,
+                                                C.c_void_p]),
     ("rtx_scene_upload", C.c_int32, [C.POINTER(RtxScene), C.c_int32, C.POINTER(C.c_void_p)]),
     ("rtx_scene_free", C.c_int32, [C.c_void_p]),
     ("rtx_scene_set_config", C.c_int32, [C.c_void_p, C.POINTER(RtxConfig)]),

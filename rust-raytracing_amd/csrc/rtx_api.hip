@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace rtx;
@@ -85,6 +86,16 @@ struct RtxSceneHandle_ {
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
     RowsView *d_rv = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    // The handle's device buffers (descriptors, tables, counters, scratch) are shared by all of its renders, so they
+    // are ordered on ONE stream at a time: when a call brings a different stream the previous one is drained first.
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
+    // Round-bound watchdog of the sweep kernel (ctr[1].pad_): copied to this pinned word after every launch and looked
+    // at by the next entry point that finds the copy complete (and by rtx_scene_free), so that the asynchronous
+    // stats == NULL path reports it too.
+    unsigned long long *h_watchdog = nullptr;
+    hipEvent_t ev_watchdog = nullptr;
+    bool watchdog_pending = false;
     // what the trig tables currently hold
     uint32_t t_w = 0, t_h = 0, t_rb = 0, t_rs = 0, t_nr = 0;
     double t_fov = 0.0;
@@ -151,6 +162,8 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->work_counter) (void)hipFree(h->work_counter);
     if (h->d_sv) (void)hipFree(h->d_sv);
     if (h->d_rv) (void)hipFree(h->d_rv);
+    if (h->h_watchdog) (void)hipHostFree(h->h_watchdog);
+    if (h->ev_watchdog) (void)hipEventDestroy(h->ev_watchdog);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -159,6 +172,8 @@ void free_handle(RtxSceneHandle_ *h)
 
 // Everything rtx_scene_upload prepares on the host: per-type shape arrays with scene-order ids, the ray-independent
 // precompute, the f32 filter records and the BVH.  No HIP call in here (rtx_debug_host_scene runs it without a GPU).
+namespace {
+
 struct PackedScene {
     SceneView sv{};
     std::vector<SphereX> spheres; std::vector<uint32_t> sphere_id;
@@ -328,12 +343,11 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     return RTX_OK;
 }
 
-// Packs `scene`'s objects and puts them (shape arrays, filter records, BVH) on the handle's device, replacing what
-// was there.  Config and camera of the handle are kept.
-int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
+// Puts a packed scene (shape arrays, filter records, BVH) on the handle's device, replacing what was there.  Config
+// and camera of the handle are kept.  The new arrays are uploaded first and swapped in on success, so a failure
+// leaves the resident scene as it was.
+int32_t upload_packed(RtxSceneHandle_ *h, const PackedScene &p)
 {
-    PackedScene p;
-    if (int32_t prc = pack_scene(scene, p)) return prc;
     const SceneView sv_before = h->sv;                    // restored if an upload fails: the handle then still holds the old scene
     std::vector<void *> old_allocs;
     old_allocs.swap(h->scene_allocs);
@@ -348,26 +362,19 @@ int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
     h->sv.to_world_x = mk(h->cam.to_world_space[0], h->cam.to_world_space[1], h->cam.to_world_space[2]);
     h->sv.to_world_y = mk(h->cam.to_world_space[3], h->cam.to_world_space[4], h->cam.to_world_space[5]);
     h->sv.to_world_z = mk(h->cam.to_world_space[6], h->cam.to_world_space[7], h->cam.to_world_space[8]);
-    const std::vector<SphereX> &spheres = p.spheres; const std::vector<uint32_t> &sphere_id = p.sphere_id;
-    const std::vector<PlaneX> &planes = p.planes; const std::vector<TriX> &tris = p.tris;
-    const std::vector<MaterialX> &mats = p.mats;
-    const std::vector<float4> &sph32 = p.sph32, &tri32 = p.tri32, &leaf32 = p.leaf32;
-    const std::vector<uint32_t> &tri_fidx = p.tri_fidx;
-    const BvhBuild &bvh = p.bvh;
-    const Bvh4Build &bvh4 = p.bvh4;
 
     int32_t rc = RTX_OK;
-    if (!rc) rc = upload_vec(h, bvh4.nodes, &h->sv.bvh_nodes);
-    if (!rc) rc = upload_vec(h, bvh.prims, &h->sv.bvh_prims);
-    if (!rc) rc = upload_vec(h, leaf32, &h->sv.bvh_leaf_f32);
-    if (!rc) rc = upload_vec(h, spheres, &h->sv.spheres);
-    if (!rc) rc = upload_vec(h, sphere_id, &h->sv.sphere_id);
-    if (!rc) rc = upload_vec(h, planes, &h->sv.planes);
-    if (!rc) rc = upload_vec(h, tris, &h->sv.tris);
-    if (!rc) rc = upload_vec(h, mats, &h->sv.materials);
-    if (!rc) rc = upload_vec(h, sph32, &h->sv.sphere_f32);
-    if (!rc) rc = upload_vec(h, tri32, &h->sv.tri_f32);
-    if (!rc) rc = upload_vec(h, tri_fidx, &h->sv.tri_fidx);
+    if (!rc) rc = upload_vec(h, p.bvh4.nodes, &h->sv.bvh_nodes);
+    if (!rc) rc = upload_vec(h, p.bvh.prims, &h->sv.bvh_prims);
+    if (!rc) rc = upload_vec(h, p.leaf32, &h->sv.bvh_leaf_f32);
+    if (!rc) rc = upload_vec(h, p.spheres, &h->sv.spheres);
+    if (!rc) rc = upload_vec(h, p.sphere_id, &h->sv.sphere_id);
+    if (!rc) rc = upload_vec(h, p.planes, &h->sv.planes);
+    if (!rc) rc = upload_vec(h, p.tris, &h->sv.tris);
+    if (!rc) rc = upload_vec(h, p.mats, &h->sv.materials);
+    if (!rc) rc = upload_vec(h, p.sph32, &h->sv.sphere_f32);
+    if (!rc) rc = upload_vec(h, p.tri32, &h->sv.tri_f32);
+    if (!rc) rc = upload_vec(h, p.tri_fidx, &h->sv.tri_fidx);
     if (rc) {
         for (void *d : h->scene_allocs) (void)hipFree(d);
         h->scene_allocs.swap(old_allocs);
@@ -378,6 +385,91 @@ int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
     h->sv_dirty = true;
     return RTX_OK;
 }
+
+int32_t install_scene(RtxSceneHandle_ *h, const RtxScene *scene)
+{
+    PackedScene p;
+    if (int32_t prc = pack_scene(scene, p)) return prc;
+    return upload_packed(h, p);
+}
+
+int32_t check_scene_args(const RtxScene *scene, const char *who)
+{
+    if (!scene) return fail(RTX_ERR_INVALID_ARGUMENT, std::string(who) + ": null scene");
+    if (scene->n_objects && !scene->objects) return fail(RTX_ERR_INVALID_ARGUMENT, std::string(who) + ": objects is null");
+    if (scene->n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, std::string(who) + ": too many objects");
+    return check_config(scene->config);
+}
+
+int32_t check_device(int32_t device, const char *who)
+{
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        (void)hipGetLastError();
+        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; librtx_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, std::string(who) + ": bad device index");
+    if (!device_is_gfx950(device)) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library targets gfx950 only");
+    return RTX_OK;
+}
+
+// A handle on `device` holding an already packed scene (one pack serves every device of rtx_render_devices).
+int32_t create_handle(const RtxScene *scene, const PackedScene &p, int32_t device, RtxSceneHandle_ **out)
+{
+    *out = nullptr;
+    RTX_HIP_CHECK(hipSetDevice(device));
+    RtxSceneHandle_ *h = new RtxSceneHandle_();
+    h->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, "hipGetDeviceProperties failed"); }
+    h->n_cus = prop.multiProcessorCount;
+    h->cam = scene->camera;
+    apply_config(h, scene->config);
+    if (int32_t irc = upload_packed(h, p)) { free_handle(h); return irc; }
+    h->objects.assign(scene->objects, scene->objects + scene->n_objects);
+
+    hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_sv, sizeof(SceneView));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_rv, sizeof(RowsView));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_watchdog, sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) { *h->h_watchdog = 0ull; e = hipEventCreateWithFlags(&h->ev_watchdog, hipEventDisableTiming); }
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
+    if (e != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, std::string("scene scratch: ") + hipGetErrorString(e)); }
+    *out = h;
+    return RTX_OK;
+}
+
+// The watchdog word of the last launch, if its copy has arrived (wait = true: drain the stream first).
+int32_t check_watchdog(RtxSceneHandle_ *h, bool wait)
+{
+    if (!h->watchdog_pending) return RTX_OK;
+    if (wait) RTX_HIP_CHECK(hipEventSynchronize(h->ev_watchdog));
+    else {
+        const hipError_t q = hipEventQuery(h->ev_watchdog);
+        if (q == hipErrorNotReady) return RTX_OK;            // still running: looked at by a later call
+        RTX_HIP_CHECK(q);
+    }
+    h->watchdog_pending = false;
+    if (*h->h_watchdog != 0ull) {
+        const unsigned long long n = *h->h_watchdog;
+        *h->h_watchdog = 0ull;
+        return fail(RTX_ERR_HIP, "an earlier render on this scene hit the sweep kernel's round bound (internal error): " +
+                                     std::to_string(n) + " workgroup(s) left early; its image is incomplete");
+    }
+    return RTX_OK;
+}
+
+// Orders a call on `stream` after everything the handle enqueued on the stream it used before.
+int32_t adopt_stream(RtxSceneHandle_ *h, hipStream_t stream)
+{
+    if (h->have_last_stream && h->last_stream != stream) RTX_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    h->last_stream = stream;
+    h->have_last_stream = true;
+    return RTX_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -421,49 +513,27 @@ int32_t rtx_scene_upload(const RtxScene *scene, int32_t device, RtxSceneHandle *
 {
     if (!scene || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: null argument");
     *out = nullptr;
-    if (scene->n_objects && !scene->objects) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: objects is null");
-    if (scene->n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: too many objects");
-    if (int32_t rc = check_config(scene->config)) return rc;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
-        (void)hipGetLastError();
-        return fail(RTX_ERR_NO_DEVICE, "no HIP device visible; librtx_hip has no CPU fallback");
-    }
-    if (device < 0 || device >= n_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_upload: bad device index");
-    if (!device_is_gfx950(device)) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library targets gfx950 only");
-    RTX_HIP_CHECK(hipSetDevice(device));
-
-    RtxSceneHandle_ *h = new RtxSceneHandle_();
-    h->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, "hipGetDeviceProperties failed"); }
-    h->n_cus = prop.multiProcessorCount;
-    h->cam = scene->camera;
-    apply_config(h, scene->config);
-
-    if (int32_t irc = install_scene(h, scene)) { free_handle(h); return irc; }
-    h->objects.assign(scene->objects, scene->objects + scene->n_objects);
-
-    hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_sv, sizeof(SceneView));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_rv, sizeof(RowsView));
-    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
-    if (e != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, std::string("scene scratch: ") + hipGetErrorString(e)); }
-    *out = h;
-    return RTX_OK;
+    if (int32_t rc = check_scene_args(scene, "rtx_scene_upload")) return rc;
+    if (int32_t rc = check_device(device, "rtx_scene_upload")) return rc;
+    PackedScene p;
+    if (int32_t rc = pack_scene(scene, p)) return rc;
+    return create_handle(scene, p, device, out);
 }
 
 int32_t rtx_scene_free(RtxSceneHandle scene)
 {
+    if (!scene) return RTX_OK;
+    (void)hipSetDevice(scene->device);
+    const int32_t rc = check_watchdog(scene, true);         // the last chance to report a render that left early
     free_handle(scene);
-    return RTX_OK;
+    return rc;
 }
 
 int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config)
 {
     if (!scene || !config) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_set_config: null argument");
     if (int32_t rc = check_config(*config)) return rc;
+    if (int32_t rc = check_watchdog(scene, false)) return rc;
     apply_config(scene, *config);
     return RTX_OK;
 }
@@ -471,6 +541,7 @@ int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config)
 int32_t rtx_scene_set_camera(RtxSceneHandle scene, const RtxCamera *camera)
 {
     if (!scene || !camera) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_set_camera: null argument");
+    if (int32_t rc = check_watchdog(scene, false)) return rc;
     scene->cam = *camera;
     scene->sv.cam_pos = mk(camera->position[0], camera->position[1], camera->position[2]);
     scene->sv.to_world_x = mk(camera->to_world_space[0], camera->to_world_space[1], camera->to_world_space[2]);
@@ -487,6 +558,7 @@ int32_t rtx_scene_append_objects(RtxSceneHandle scene, const RtxObject *objects,
     if (scene->objects.size() + n_objects > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_append_objects: too many objects");
     RTX_HIP_CHECK(hipSetDevice(scene->device));
     RTX_HIP_CHECK(hipDeviceSynchronize());                  // a render may still read the arrays about to be replaced
+    if (int32_t rc = check_watchdog(scene, true)) return rc;
     std::vector<RtxObject> all = scene->objects;
     all.insert(all.end(), objects, objects + n_objects);
     RtxScene sc{};
@@ -512,9 +584,23 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: rows exceed the image height");
     if ((uint64_t)n_rows * width > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: more than 2^32 pixels per call");
     RTX_HIP_CHECK(hipSetDevice(h->device));
+    if (int32_t rc = check_watchdog(h, false)) return rc;
+    if (int32_t rc = adopt_stream(h, stream)) return rc;
 
     const uint32_t npix = n_rows * width;
     const uint64_t spp = h->cfg.rays_per_pixel;
+    if (h->sv.n_objects == 0 && spp > 0) {
+        // render_ray of an empty scene returns resulting_color = 0 for every sample (scene.rs:224-226) and avg() of
+        // zeros is 0/len = +0.0: nothing to trace.  (The sweep kernel's workgroups leave as soon as a round finds no
+        // live slot, which an empty scene produces at once: most sample planes would stay unwritten.)
+        RTX_HIP_CHECK(hipMemsetAsync(d_out_rgb, 0, (size_t)npix * 3 * sizeof(double), stream));
+        if (stats) {
+            RTX_HIP_CHECK(hipStreamSynchronize(stream));
+            stats->primary_rays = (uint64_t)npix * spp;
+            stats->kernel = h->cfg.kernel;
+        }
+        return RTX_OK;
+    }
     // samples per launch: all of them unless the sample planes would exceed the scratch cap
     uint64_t batch = spp;
     {
@@ -649,6 +735,15 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             trace_ms += a; resolve_ms += b;
         }
     }
+    if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
+        // round-bound watchdog of the sweep kernel (ctr[1].pad_, sticky within this call): mirrored to a pinned word
+        // and looked at by the next entry point that finds the copy complete, whether or not stats were asked for
+        if (h->watchdog_pending) RTX_HIP_CHECK(hipEventSynchronize(h->ev_watchdog));
+        if (int32_t rc = check_watchdog(h, false)) return rc;
+        RTX_HIP_CHECK(hipMemcpyAsync(h->h_watchdog, &h->counters[1].pad_, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        RTX_HIP_CHECK(hipEventRecord(h->ev_watchdog, stream));
+        h->watchdog_pending = true;
+    }
     if (stats) {
         RTX_HIP_CHECK(hipStreamSynchronize(stream));
         Counters host[kCounterShards];
@@ -660,9 +755,11 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         }
         stats->filter_mismatches = host[0].pad_;
         for (int k = 2; k < kCounterShards; ++k) stats->box_tests += host[k].pad_;
-        if (host[1].pad_ != 0)
+        if (host[1].pad_ != 0) {
+            h->watchdog_pending = false; *h->h_watchdog = 0ull;        // reported right here
             return fail(RTX_ERR_HIP, "trace kernel hit its round bound (internal error): " + std::to_string(host[1].pad_) +
                                          " workgroup(s) left early");
+        }
         stats->primary_rays = (uint64_t)npix * spp;
         stats->trace_ms = trace_ms;
         stats->resolve_ms = resolve_ms;
@@ -682,48 +779,132 @@ int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t 
     return RTX_OK;
 }
 
-static int32_t render_common(const RtxScene *scene, uint32_t width, uint32_t height, double *out_rgb, uint8_t *out_rgb8)
+// Scene::render / render_to_image over a list of devices (one entry = rtx_render's single-GPU form).
+//
+// The frame is partitioned into interleaved row bands (device k of n renders rows y = k, k + n, ...: interleaving
+// balances the uneven per-pixel cost), the scene is packed ONCE on the host and replicated, one host thread per
+// device uploads, renders its band (rtx_render_rows, asynchronously on the thread's own stream) and hands the band to
+// the staging buffer on devices[0]; then one de-interleave kernel (+ the u8 epilogue) and ONE device-to-host copy.
+// There is no exchange during the render (pixels are independent, scene.rs:149-160).
+//
+// The gather is hipMemcpyPeerAsync, not RCCL: inside one process the bands are n - 1 independent point-to-point
+// copies into disjoint regions of one buffer -- each peer's DMA engine pushes over its own xGMI link to devices[0], which
+// is what a gather does on this topology -- and a peer copy needs no communicator (ncclCommInitAll costs more than a
+// C2 frame) and accepts a device list with repeated entries, which is how the path is tested on a one-GPU box.  The
+// process-per-GPU form of the same partition (bench.py, rust-raytracing_amd/tiles.py) gathers with RCCL.
+static int32_t render_common(const RtxScene *scene, uint32_t width, uint32_t height, const int32_t *devices, uint32_t n_dev,
+                             double *out_rgb, uint8_t *out_rgb8)
 {
-    if (!scene) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null scene");
+    if (int32_t rc = check_scene_args(scene, "rtx_render")) return rc;
     const uint64_t npix = (uint64_t)width * height;
     if (npix == 0) return RTX_OK;                     // vec![vec![..; 0]; h] renders nothing (scene.rs:146)
     if (!out_rgb && !out_rgb8) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null output");
-    RtxSceneHandle h = nullptr;
-    if (int32_t rc = rtx_scene_upload(scene, 0, &h)) return rc;
-    double *d_out = nullptr;
+    if (n_dev == 0 || !devices) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_devices: empty device list");
+    if (n_dev > 64) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_devices: more than 64 devices");
+    for (uint32_t k = 0; k < n_dev; ++k)
+        if (int32_t rc = check_device(devices[k], "rtx_render_devices")) return rc;
+    PackedScene packed;
+    if (int32_t rc = pack_scene(scene, packed)) return rc;
+
+    const int dev0 = devices[0];
+    const uint32_t cap_rows = (height + n_dev - 1) / n_dev;                   // rows of the largest band
+    const size_t band_doubles = (size_t)cap_rows * width * 3;
+    double *d_parts = nullptr, *d_full = nullptr;
     uint8_t *d_q = nullptr;
-    int32_t rc = RTX_OK;
-    hipError_t e = hipMalloc((void **)&d_out, npix * 3 * sizeof(double));
+    RTX_HIP_CHECK(hipSetDevice(dev0));
+    hipError_t e = hipMalloc((void **)&d_parts, band_doubles * n_dev * sizeof(double));
+    if (e == hipSuccess && n_dev > 1) e = hipMalloc((void **)&d_full, npix * 3 * sizeof(double));
     if (e == hipSuccess && out_rgb8) e = hipMalloc((void **)&d_q, npix * 3);
+    int32_t rc = RTX_OK;
     if (e != hipSuccess) rc = fail(RTX_ERR_OUT_OF_MEMORY, std::string("rtx_render: ") + hipGetErrorString(e));
-    RtxStats st;
+
+    struct Worker { int32_t rc = RTX_OK; std::string msg; };
+    std::vector<Worker> res(n_dev);
     const bool dbg = std::getenv("RTX_HIP_DEBUG") != nullptr;
-    if (!rc) rc = rtx_render_rows(h, width, height, 0, 1, height, d_out, nullptr, &st);
-    if (!rc && dbg)
-        std::fprintf(stderr, "[rtx_hip] rays %llu segments %llu exact %llu filter %llu mismatches %llu trace %.3f ms resolve %.3f ms\n",
-                     (unsigned long long)st.primary_rays, (unsigned long long)st.segments, (unsigned long long)st.exact_tests,
-                     (unsigned long long)st.filter_tests, (unsigned long long)st.filter_mismatches, st.trace_ms, st.resolve_ms);
-    if (!rc && out_rgb8) rc = rtx_quantize_image_device(d_out, width, height, d_q, 0, nullptr);
+    auto work = [&](uint32_t k) {
+        Worker &w = res[k];
+        const int dev = devices[k];
+        RtxSceneHandle_ *h = nullptr;
+        hipStream_t stream = nullptr;
+        double *d_band = nullptr;
+        const uint32_t n_rows = k < height ? (height - k + n_dev - 1) / n_dev : 0u;
+        auto step = [&](int32_t r) { if (r && !w.rc) { w.rc = r; w.msg = g_last_error; } return w.rc == RTX_OK; };
+        auto hip = [&](hipError_t he, const char *what) {
+            if (he != hipSuccess && !w.rc) { w.rc = he == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP; w.msg = std::string(what) + ": " + hipGetErrorString(he); }
+            return w.rc == RTX_OK;
+        };
+        if (step(create_handle(scene, packed, dev, &h)) && hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate")) {
+            double *dst = d_parts + (size_t)k * band_doubles;           // this band's region of the staging buffer on devices[0]
+            if (dev == dev0) d_band = dst;                              // render straight into it
+            else {
+                int can = 0;                                            // direct xGMI DMA when the pair allows it (else the copy is staged)
+                if (hipDeviceCanAccessPeer(&can, dev, dev0) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(dev0, 0);
+                (void)hipGetLastError();                                // "already enabled" is not an error
+                hip(hipMalloc((void **)&d_band, band_doubles * sizeof(double)), "hipMalloc(band)");
+            }
+            RtxStats st;
+            if (w.rc == RTX_OK && n_rows) step(rtx_render_rows(h, width, height, k, n_dev, n_rows, d_band, stream, dbg ? &st : nullptr));
+            if (w.rc == RTX_OK && n_rows && dbg)
+                std::fprintf(stderr, "[rtx_hip] device %d band %u/%u: rays %llu segments %llu exact %llu filter %llu mismatches %llu trace %.3f ms resolve %.3f ms\n",
+                             dev, k, n_dev, (unsigned long long)st.primary_rays, (unsigned long long)st.segments, (unsigned long long)st.exact_tests,
+                             (unsigned long long)st.filter_tests, (unsigned long long)st.filter_mismatches, st.trace_ms, st.resolve_ms);
+            if (w.rc == RTX_OK && n_rows && dev != dev0)
+                hip(hipMemcpyPeerAsync(dst, dev0, d_band, dev, (size_t)n_rows * width * 3 * sizeof(double), stream), "hipMemcpyPeerAsync");
+            if (stream) hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        }
+        if (h) step(rtx_scene_free(h));                                 // (reports the sweep kernel's watchdog)
+        if (d_band && dev != dev0) (void)hipFree(d_band);
+        if (stream) (void)hipStreamDestroy(stream);
+    };
     if (!rc) {
-        e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess && out_rgb) e = hipMemcpy(out_rgb, d_out, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (n_dev == 1) work(0);
+        else {
+            std::vector<std::thread> threads;
+            for (uint32_t k = 0; k < n_dev; ++k) threads.emplace_back(work, k);
+            for (auto &t : threads) t.join();
+        }
+        for (uint32_t k = 0; k < n_dev && !rc; ++k)
+            if (res[k].rc) rc = fail((RtxStatus)res[k].rc, "device " + std::to_string(devices[k]) + ": " + res[k].msg);
+    }
+    if (!rc) {
+        e = hipSetDevice(dev0);
+        const double *d_img = d_parts;                                  // one device: the band IS the frame
+        if (e == hipSuccess && n_dev > 1) { e = launch_deinterleave(d_parts, d_full, width, height, n_dev, cap_rows, nullptr); d_img = d_full; }
+        if (e == hipSuccess && out_rgb8) e = launch_quantize(d_img, d_q, width, height, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && out_rgb) e = hipMemcpy(out_rgb, d_img, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_rgb8) e = hipMemcpy(out_rgb8, d_q, npix * 3, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RTX_ERR_HIP, std::string("rtx_render: ") + hipGetErrorString(e));
     }
-    if (d_out) (void)hipFree(d_out);
+    (void)hipSetDevice(dev0);
+    if (d_parts) (void)hipFree(d_parts);
+    if (d_full) (void)hipFree(d_full);
     if (d_q) (void)hipFree(d_q);
-    rtx_scene_free(h);
     return rc;
 }
 
 int32_t rtx_render(const RtxScene *scene, uint32_t width, uint32_t height, double *out_rgb)
 {
-    return render_common(scene, width, height, out_rgb, nullptr);
+    const int32_t dev = 0;
+    return render_common(scene, width, height, &dev, 1, out_rgb, nullptr);
 }
 
 int32_t rtx_render_to_image(const RtxScene *scene, uint32_t width, uint32_t height, uint8_t *out_rgb8)
 {
-    return render_common(scene, width, height, nullptr, out_rgb8);
+    const int32_t dev = 0;
+    return render_common(scene, width, height, &dev, 1, nullptr, out_rgb8);
+}
+
+int32_t rtx_render_devices(const RtxScene *scene, uint32_t width, uint32_t height, const int32_t *devices, uint32_t n_devices,
+                           double *out_rgb)
+{
+    return render_common(scene, width, height, devices, n_devices, out_rgb, nullptr);
+}
+
+int32_t rtx_render_to_image_devices(const RtxScene *scene, uint32_t width, uint32_t height, const int32_t *devices,
+                                    uint32_t n_devices, uint8_t *out_rgb8)
+{
+    return render_common(scene, width, height, devices, n_devices, nullptr, out_rgb8);
 }
 
 int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
@@ -819,16 +1000,16 @@ int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out
     if (n == 0) return RTX_OK;
     if (!a || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_math: null argument");
     if (usable_device_count() == 0) return fail(RTX_ERR_NO_DEVICE, "no gfx950 device");
-    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    struct Bufs {                                   // freed on every return path
+        double *p[3] = { nullptr, nullptr, nullptr };
+        ~Bufs() { for (double *q : p) if (q) (void)hipFree(q); }
+    } d;
     RTX_HIP_CHECK(hipSetDevice(0));
-    RTX_HIP_CHECK(hipMalloc((void **)&da, n * sizeof(double)));
-    RTX_HIP_CHECK(hipMalloc((void **)&db, n * sizeof(double)));
-    RTX_HIP_CHECK(hipMalloc((void **)&dout, n * sizeof(double)));
-    RTX_HIP_CHECK(hipMemcpy(da, a, n * sizeof(double), hipMemcpyHostToDevice));
-    RTX_HIP_CHECK(hipMemcpy(db, b ? b : a, n * sizeof(double), hipMemcpyHostToDevice));
-    RTX_HIP_CHECK(launch_debug_math(op, da, db, dout, n, nullptr));
-    RTX_HIP_CHECK(hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    for (double *&q : d.p) RTX_HIP_CHECK(hipMalloc((void **)&q, n * sizeof(double)));
+    RTX_HIP_CHECK(hipMemcpy(d.p[0], a, n * sizeof(double), hipMemcpyHostToDevice));
+    RTX_HIP_CHECK(hipMemcpy(d.p[1], b ? b : a, n * sizeof(double), hipMemcpyHostToDevice));
+    RTX_HIP_CHECK(launch_debug_math(op, d.p[0], d.p[1], d.p[2], n, nullptr));
+    RTX_HIP_CHECK(hipMemcpy(out, d.p[2], n * sizeof(double), hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 

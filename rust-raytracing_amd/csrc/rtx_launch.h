@@ -42,6 +42,10 @@ hipError_t launch_resolve(const double *samples, double *acc, double *out, uint3
 // render_to_image epilogue (scene.rs:175-178)
 hipError_t launch_quantize(const double *rgb, uint8_t *rgb8, uint32_t width, uint32_t height, hipStream_t stream);
 
+// rtx_render_devices' gather epilogue: parts = n bands of cap_rows rows each (band k = rows k, k + n, ...) -> full frame
+hipError_t launch_deinterleave(const double *parts, double *full, uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows,
+                               hipStream_t stream);
+
 // device evaluation of single f64 ops (tests: are / and sqrt correctly rounded, how far are sin/cos)
 // op: 0 a/b, 1 sqrt(a), 2 sin(a), 3 cos(a)
 hipError_t launch_debug_math(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);

@@ -48,6 +48,99 @@ def test_struct_layouts_match_the_header(rtx, tmp_path):
     assert got[0] == 136
 
 
+def _c_struct_layouts(tmp_path):
+    """{struct: (size, [(field, offset, size), ...])} as gcc lays out include/rtx_hip.h (field lists parsed from the header)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s+\w+\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = [re.sub(r"\[.*", "", f.strip().split()[-1]).lstrip("*") for f in body.split(";") if f.strip()]
+        structs[name] = fields
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rtx_hip.h"', 'int main(void){']
+    for name, fields in structs.items():
+        lines.append('printf("S %s %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fields:
+            lines.append('printf("F %s %s %%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s *)0)->%s));' % (name, f, name, f, name, f))
+    lines.append('return 0;}')
+    prog = tmp_path / "fields.c"
+    prog.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "fields"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-I" + os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = {}
+    for ln in subprocess.check_output([str(exe)]).decode().splitlines():
+        t = ln.split()
+        if t[0] == "S":
+            out[t[1]] = (int(t[2]), [])
+        else:
+            out[t[1]][1].append((t[2], int(t[3]), int(t[4])))
+    return out
+
+
+_RUST_SCALARS = {"u8": 1, "u32": 4, "i32": 4, "u64": 8, "i64": 8, "f64": 8, "f32": 4}
+
+
+def _rust_repr_c_layouts(path):
+    """#[repr(C)] structs of a Rust source file, laid out by the C rules: {struct: (size, [(field, offset, size)])}."""
+    src = re.sub(r"//[^\n]*", "", open(path).read())
+    out = {}
+
+    def size_align(ty):
+        ty = ty.strip()
+        m = re.fullmatch(r"\[\s*(\w+)\s*;\s*(\d+)\s*\]", ty)
+        if m:
+            s, a = size_align(m.group(1))
+            return s * int(m.group(2)), a
+        if ty.startswith("*const") or ty.startswith("*mut"):
+            return 8, 8
+        if ty in _RUST_SCALARS:
+            return _RUST_SCALARS[ty], _RUST_SCALARS[ty]
+        size, fields = out[ty]                                       # a struct declared earlier in the file
+        return size, max(size_align_of_fields(ty))
+
+    aligns = {}
+
+    def size_align_of_fields(name):
+        return aligns[name]
+
+    for name, body in re.findall(r"#\[repr\(C\)\]\s*(?:#\[[^\]]*\]\s*)*pub\s+struct\s+(\w+)\s*\{(.*?)\}", src, flags=re.S):
+        off, fields, al = 0, [], [1]
+        for fname, fty in re.findall(r"(?:pub\s+)?(\w+)\s*:\s*([^,]+),", body):
+            s, a = size_align(fty)
+            off = (off + a - 1) // a * a
+            fields.append((fname, off, s))
+            off += s
+            al.append(a)
+        amax = max(al)
+        aligns[name] = al
+        out[name] = ((off + amax - 1) // amax * amax, fields)
+    return out
+
+
+def test_rust_shim_matches_the_header(tmp_path):
+    """rust/src/raytracing/hip.rs cannot be compiled here (no rustc): its #[repr(C)] structs are parsed and laid out by
+    the C rules, and must have the header's field names, order, offsets and sizes; its extern "C" block must declare
+    functions of the header with the header's argument counts."""
+    c = _c_struct_layouts(tmp_path)
+    r = _rust_repr_c_layouts(os.path.join(ROOT, "rust", "src", "raytracing", "hip.rs"))
+    for name in ("RtxObject", "RtxConfig", "RtxCamera", "RtxScene", "RtxStats"):
+        assert name in r, name
+        assert r[name] == c[name], name
+    assert c["RtxObject"][0] == 136 and c["RtxConfig"][0] == 56 and c["RtxCamera"][0] == 200 and c["RtxScene"][0] == 272
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    c_fns = {n: (0 if a.strip() in ("", "void") else a.count(",") + 1)
+             for n, a in re.findall(r"\b(rtx_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", hdr)}
+    rs = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "rust", "src", "raytracing", "hip.rs")).read())
+    ext = re.search(r'extern\s+"C"\s*\{(.*?)\n\}', rs, flags=re.S).group(1)
+    r_fns = {n: (0 if not a.strip() else a.count(":")) for n, a in re.findall(r"pub\s+fn\s+(rtx_\w+)\s*\(([^)]*)\)", ext)}
+    assert len(r_fns) >= 14
+    for n, k in r_fns.items():
+        assert n in c_fns and c_fns[n] == k, n
+    for needed in ("rtx_render", "rtx_render_to_image", "rtx_render_devices", "rtx_render_to_image_devices", "rtx_last_error"):
+        assert needed in r_fns
+    # the shim's Scene::render body goes through these and nothing else
+    body = open(os.path.join(ROOT, "rust", "patches", "scene_render.rs")).read()
+    assert set(re.findall(r"hip::(rtx_\w+)", body)) <= set(r_fns)
+
+
 def test_cpp_host_header_compiles(tmp_path):
     # include/rtx.hpp (the C++ mirror of the crate's lib.rs surface) must compile on its own
     src = tmp_path / "t.cpp"

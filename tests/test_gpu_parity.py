@@ -594,6 +594,159 @@ def test_c5_shaped_rows_of_one_rank(gpu):
     assert a[0].mean() > 0.01
 
 
+def _scattered_pixels(img, n_random, n_bright, seed):
+    """Pixels to hand to the oracle: the four corners, the last column / row (the padding of partial 8x8 tiles starts
+    right behind them), the brightest pixels of the frame (paths that found a light) and uniformly random ones."""
+    h, w, _ = img.shape
+    rng = np.random.default_rng(seed)
+    xs = [0, w - 1, 0, w - 1, w - 1, w - 1, w // 2, 3]
+    ys = [0, 0, h - 1, h - 1, h // 2, 5, h - 1, h - 1]
+    lum = img.sum(axis=2).ravel()
+    bright = np.argsort(lum)[::-1][:4 * n_bright]
+    bright = bright[lum[bright] > 0][::4][:n_bright]                # every 4th of the brightest: not all from one blob
+    xs += list(bright % w); ys += list(bright // w)
+    xs += list(rng.integers(0, w, n_random)); ys += list(rng.integers(0, h, n_random))
+    return np.asarray(xs, dtype=np.uint32), np.asarray(ys, dtype=np.uint32)
+
+
+def test_c3_full_size_against_the_oracle(gpu, oracle):
+    """BASELINE.json configs[2] on its own scene at its own size: 100k random triangles (scene seed 2), 1920x1080, AUTO
+    (= the regrouping BVH kernel).  (1) two renders are bit-identical, (2) segments within [rays, 11 rays], (3) 300+
+    scattered pixels -- corners, edge columns, the brightest pixels, random ones -- equal the oracle's
+    (rtxo_render_pixels: every triangle tested per segment, triangle.rs:108-127, scene.rs:243-251) within ATOL,
+    (4) the lock-step BVH kernel produces the same frame bit for bit."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.random_triangles(100000, 2)
+    w, h, spp = 1920, 1080, 2
+    sc = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, seed=42), gpu.Camera(*scenes.CAMERA), objs)
+    hnd = sc.upload(0)
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    a = buf.cpu().numpy()
+    buf.zero_()
+    hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    assert np.array_equal(a, buf.cpu().numpy())
+    assert st.kernel == gpu.RTX_KERNEL_BVH_REGROUP
+    assert st.primary_rays == w * h * spp and w * h * spp <= st.segments <= 11 * w * h * spp
+    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_BVH))
+    buf.zero_()
+    st2 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    assert np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
+    hnd.close()
+    xs, ys = _scattered_pixels(a, 200, 100, seed=11)
+    assert len(xs) >= 256
+    osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=spp, seed=42)
+    ref = oracle.render_pixels(osc, w, h, xs, ys)
+    got = a[ys, xs]
+    assert max_abs_diff(got, ref) <= ATOL
+    assert (ref.sum(axis=1) > 0).sum() >= 50 and a.mean() > 1e-4
+
+
+def test_c5_band_against_the_oracle(gpu, oracle):
+    """BASELINE.json configs[4] on its own scene: 1M random triangles (scene seed 3, box x2), 3840x2160, the band rank 5
+    of 8 owns (270 interleaved rows), AUTO (= regrouping BVH kernel, deep tree -> the HBM stack-spill variant).
+    100+ scattered pixels of the band against the oracle, which tests all 10^6 triangles per segment."""
+    import torch
+    from rust_raytracing_amd import scenes, tiles
+    objs = scenes.random_triangles(1000000, 3, box=2.0)
+    w, h, world, rank, spp = 3840, 2160, 8, 5, 1
+    rb, rs, n = tiles.rows_for_rank(h, rank, world)
+    hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, seed=42), gpu.Camera(*scenes.CAMERA), objs).upload(0)
+    band = tiles.alloc_band(h, w, world, "cuda:0")
+    st = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+    hnd.close()
+    assert st.kernel == gpu.RTX_KERNEL_BVH_REGROUP and st.primary_rays == n * w * spp
+    assert n * w * spp <= st.segments <= 11 * n * w * spp
+    got = band[:n].cpu().numpy()
+    xs, ks = _scattered_pixels(got, 64, 40, seed=12)            # ks = row index inside the band
+    ys = (rb + ks.astype(np.int64) * rs).astype(np.uint32)
+    osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=spp, seed=42)
+    ref = oracle.render_pixels(osc, w, h, xs, ys)
+    assert max_abs_diff(got[ks, xs], ref) <= ATOL
+    assert (ref.sum(axis=1) > 0).sum() >= 20
+
+
+def test_empty_scene_with_more_rays_than_resident_slots(gpu):
+    """Scene::default().render(w, h): every pixel is 0 (scene.rs:224-226) -- at a size where the rays outnumber what the
+    persistent kernels hold at once (the sweep kernel left early before the host short-circuit existed), on a handle
+    that has already rendered something else into its scratch, for AUTO and every explicit kernel."""
+    import torch
+    from rust_raytracing_amd import scenes
+    w, h = 1024, 600
+    buf = torch.empty((h, w, 3), dtype=torch.float64, device="cuda:0")
+    for kern in [gpu.RTX_KERNEL_AUTO] + _kernels(gpu):
+        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=1, seed=1, kernel=kern), gpu.Camera(*scenes.CAMERA),
+                                    scenes.three_spheres()).upload(0)
+        hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        assert float(buf.abs().sum()) > 0
+        hnd.close()
+        empty = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=1, seed=1, kernel=kern), gpu.Camera(*scenes.CAMERA),
+                                      np.zeros(0, dtype=gpu.OBJECT_DTYPE)).upload(0)
+        buf.fill_(7.0)
+        st = empty.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        assert st.primary_rays == w * h and st.segments == 0
+        assert not bool(buf.any()), kern
+        buf.fill_(7.0)
+        empty.render_rows(w, h, 0, 1, h, buf.data_ptr(), want_stats=False)      # the asynchronous path
+        torch.cuda.synchronize()
+        assert not bool(buf.any()), kern
+        empty.close()
+    img = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=3), gpu.Camera(*scenes.CAMERA), np.zeros(0, dtype=gpu.OBJECT_DTYPE)).render(w, h)
+    assert img.shape == (h, w, 3) and not img.any()
+
+
+def test_render_devices_partition_is_invisible(gpu, oracle):
+    """rtx_render_devices (multi-GPU behind the C ABI): the device list [0, 0] and [0, 0, 0] put two / three bands --
+    separate handles, host threads and streams -- on this box's one GPU; the gathered, de-interleaved frame equals
+    rtx_render's bit for bit, for f64 and for the u8 epilogue, heights that do not divide evenly and a height smaller
+    than the device count."""
+    from rust_raytracing_amd import scenes
+    objs = scenes.mixed_scene(60, 50, 2, seed=21)
+    sc = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=3, seed=42), gpu.Camera(*scenes.CAMERA), objs)
+    for (w, h) in ((67, 41), (16, 2)):
+        one = sc.render(w, h)
+        assert max_abs_diff(one, oracle_render(oracle, objs, w, h, rays_per_pixel=3, seed=42)) <= ATOL
+        for devs in ([0], [0, 0], [0, 0, 0]):
+            assert np.array_equal(sc.render(w, h, devices=devs), one), (w, h, devs)
+        assert np.array_equal(sc.render_to_image(w, h, devices=[0, 0]), sc.render_to_image(w, h))
+    big = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*scenes.CAMERA), scenes.random_spheres(10000, 1))
+    assert np.array_equal(big.render(480, 270, devices=[0, 0]), big.render(480, 270))
+    with pytest.raises(gpu.RtxError):
+        sc.render(8, 8, devices=[])
+    with pytest.raises(gpu.RtxError):
+        sc.render(8, 8, devices=[0, 99])
+
+
+def test_handle_orders_its_work_across_streams(gpu):
+    """A handle's descriptors, tables and scratch are shared by its renders: switching streams between calls (band A on
+    s1, then a camera change + band B on s2, nothing synchronised by the caller) must give the frames of two
+    separate synchronous renders."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.random_spheres(10000, 1)
+    w, h = 640, 360
+    cam2 = ((0.0, 0.5, 0.2), (1.0, 0.1, 0.0), 1.3)
+    ref = []
+    for cam in (scenes.CAMERA, cam2):
+        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*cam), objs).upload(0)
+        b = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        hnd.render_rows(w, h, 0, 1, h, b.data_ptr())
+        ref.append(b.cpu().numpy())
+        hnd.close()
+    hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*scenes.CAMERA), objs).upload(0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    b = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    hnd.render_rows(w, h, 0, 1, h, a.data_ptr(), stream=s1.cuda_stream, want_stats=False)
+    hnd.set_camera(gpu.Camera(*cam2))
+    hnd.render_rows(w, h, 0, 1, h, b.data_ptr(), stream=s2.cuda_stream, want_stats=False)
+    torch.cuda.synchronize()
+    hnd.close()
+    assert np.array_equal(a.cpu().numpy(), ref[0]) and np.array_equal(b.cpu().numpy(), ref[1])
+
+
 def test_c2_full_size_properties(gpu, oracle):
     """10k spheres at 1920x1080 (1 spp here; the oracle cannot do this size in seconds):
     (1) a band of rows agrees with the oracle, (2) two renders are bit-identical (determinism),
