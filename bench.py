@@ -1,49 +1,79 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's headline metric on MI355X: Mrays/s (primary rays, whole node) of the
-Scene::render hot path on the 10k-sphere 1920x1080 scene (configs[1], "C2").
+"""bench.py -- BASELINE.json's headline metric on MI355X: Mrays/s (primary rays, whole node) + achieved HBM GB/s of the
+Scene::render hot path on the 10k-sphere 1920x1080 64-spp scene (configs[1], "C2"), at 1/2/4/8 GPUs.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A step = one full render of the frame: every rank traces its interleaved row band of the image (scene resident
-in HBM before the timed region), then ONE gather (RCCL over xGMI) brings the bands to rank 0.  Scaling is weak:
-the frame is fixed at 1920x1080 and rays_per_pixel = 64 * N, so every GPU traces the same number of primary
-rays (132.7 M) whatever N is.  value = all ranks' primary rays / (max-over-ranks time of the K steps).
+A step = one render of THE frame the metric names: 1920x1080 at 64 rays per pixel in total, whatever N is (STRONG
+scaling).  Rank r of N traces the interleaved row band y = r, r + N, ... (scene resident in HBM before the timed
+region), then ONE gather (RCCL over xGMI) brings the bands to rank 0 -- inside the timed region.
+value = 1920*1080*64 * K / (max-over-ranks time of the K steps).  --weak multiplies rays_per_pixel by N instead
+(fixed rays per GPU; labelled as such, not the metric).  --config C3|C4|C5 benches another BASELINE.json config as the
+primary workload (C4 = 3840x2160 at 1024 spp is the one named for 8 GPUs).
 
-Kernels (all produce the same bits; tests/test_gpu_parity.py):
-  --kernel 0  AUTO (default) = the flat-BVH kernel for this scene          -> `value`, `roofline`
-  --kernel 2  the LDS-staged f32-filter sweep named in BASELINE.json configs[1]; at N=1 it is ALSO timed after the
-              main measurement and reported as `lds_sweep` (own roofline), so both designs are on record
-  --kernel 1  exact f64 sweep (parity kernel)
+At N = 1 with the default config the line also carries
+  other_configs   C3 (full frame), C4 and C5 (the band one rank of 8 owns) at a stated reduced spp: rate + roofline each
+  lds_sweep       the LDS-staged f32-filter sweep BASELINE.json's configs[1] describes, same frame, same bits
+  cpu_baseline    the CPU oracle on this host's cores, on a sub-sample of the SAME 1920x1080 view
 
-roofline (dominant kernel = the trace kernel of rank 0): algorithmic bytes per launch / average launch duration
-measured with hipEvents on the launch stream, against the 8 TB/s HBM peak.
-  BVH kernel:   bytes = box_tests*32 + leaf_filter_tests*16 + exact_tests*32 + hits*56  (all counted by the kernel)
-  LDS sweep:    bytes = segments * n_spheres * 16.  The list is LDS/L2-resident by design, so frac may
-                exceed 1: that kernel is VALU-bound, and valu_frac gives the fraction of the VALU issue ceiling.
-cpu_baseline: the CPU oracle (a C restatement of the reference's CPU path: kind "port"; the Rust crate cannot be
-built here) timed on this host's cores on a bounded sample of the same scene.
+roofline (per kernel the rate comes from).  The path is VALU-issue bound, not HBM bound: the tree and the
+filter records are served by L2 / LDS.  So:
+  bound      "valu"
+  peak       256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.64 T lane-ops/s (MI355X_MICROARCH.md)
+  achieved   lane-ops the kernel ISSUED per launch (rocprofv3 SQ_THREAD_CYCLES_VALU = sum over VALU instructions of their
+             active lanes) / the average launch duration measured here with hipEvents on the launch stream;
+             frac = achieved / peak  (<= 1 by construction).  lane_utilisation = active lanes per VALU instruction / 64.
+  traffic    HBM-side bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE (separate passes; FETCH doubled as the
+             guide prescribes for gfx950, raw figure beside it); hbm_gbs = traffic / launch time, hbm_frac = / 8 TB/s
+  algorithmic  what the kernel counted itself in this run (box tests, filter tests, exact tests) priced in lane-ops and
+             bytes -- the figure that needs no profiler
+The counters are collected IN THIS RUN when rocprofv3 is on the PATH (child processes `rocprofv3 --pmc ... -- python3
+bench.py --pmc-leg ...` after the timed region; --no-pmc skips them); otherwise they are read from profiles/pmc_counters.json
+if its kernel-source hash matches this tree, else the fields are null and `counters_source` says so.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch                       # noqa: E402  (first: one HIP runtime for torch tensors and librtx_hip)
-import torch.distributed as dist   # noqa: E402
-
-WIDTH, HEIGHT, SPP_PER_GPU, N_SPHERES = 1920, 1080, 64, 10000
-HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9      # 256 CU x 4 SIMD-32 x 2.4 GHz
-FILTER_OPS_PER_TEST = 8.0          # lane-ops of the f32 sphere filter per (ray, sphere): 7 fma + 1 add
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 78.64: one wave64 VALU instruction per 2 cycles per SIMD-32
+CONFIGS = {
+    "C2": dict(scene="spheres", n=10000, seed=1, box=1.0, w=1920, h=1080, spp=64,
+               name="10k random spheres (scene seed 1), 1920x1080"),
+    "C3": dict(scene="triangles", n=100000, seed=2, box=1.0, w=1920, h=1080, spp=64,
+               name="100k random triangles (scene seed 2), 1920x1080"),
+    "C4": dict(scene="spheres", n=10000, seed=1, box=1.0, w=3840, h=2160, spp=1024,
+               name="10k random spheres (scene seed 1), 3840x2160"),
+    "C5": dict(scene="triangles", n=1000000, seed=3, box=2.0, w=3840, h=2160, spp=256,
+               name="1M random triangles (scene seed 3, box x2), 3840x2160, flat BVH"),
+}
 KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 filter sweep + exact f64 (trace_mixed_kernel)",
-                3: "trace_mixed_kernel + verify", 4: "flat 4-wide BVH + f32 filter + exact f64 (trace_bvh_kernel)"}
+                3: "trace_mixed_kernel + verify", 4: "flat 4-wide BVH, lock-step waves (trace_bvh_kernel)",
+                5: "flat 4-wide BVH, regrouping schedule (trace_bvh_regroup_kernel)"}
+KERNEL_SYMBOL = {1: "trace_exact_kernel", 2: "trace_mixed_kernel", 3: "trace_mixed_kernel", 4: "trace_bvh_kernel",
+                 5: "trace_bvh_regroup_kernel"}
+# lane-op prices of the algorithmic counts (what the chosen algorithm needs at least; f64 instructions issue at half rate
+# and count double).  box test: 6 fma + 9 min/max + 2 mul + 2 cmp; sphere filter: 7 fma + 1 sub; triangle filter: 16;
+# exact sphere test (sphere.rs:19-30): 17 f64 add/mul + sqrt + div (~14 f64 instructions each) = 45 f64 -> 90; exact
+# triangle test (triangle.rs:108-127): ~40 f64 add/mul + 3 div = 82 f64 -> 164; LDS-sweep filter: 8 per (ray, sphere).
+LANE_OPS = {"box": 19.0, "sphere_filter": 8.0, "tri_filter": 16.0, "sphere_exact": 90.0, "tri_exact": 164.0}
+PMC_PASSES = (("fetch", ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]), ("write", ["WRITE_SIZE"]),
+              ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                      "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]))
 
 
 def parse():
@@ -51,47 +81,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=None, help="rays per pixel per GPU (default 64: the named config)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json config benched as the primary workload")
+    ap.add_argument("--spp", type=int, default=None, help="total rays per pixel (default: the config's own, 64 for C2)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: rays_per_pixel = spp * N (fixed rays per GPU); not the metric")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH lock-step, 5 BVH regroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds-sweep", action="store_true", help="skip the secondary measurement of the LDS sweep kernel")
-    ap.add_argument("--cpu-sample", default="240x135x1", help="WxHxSPP sample of the same scene for the CPU leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip C3 / C4 band / C5 band at N = 1")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect rocprofv3 counters in this run")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of each cpu_baseline mode")
+    ap.add_argument("--other-spp", default="C3=8,C4=64,C5=4", help="rays per pixel of the other_configs legs")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the gather goes through gloo on host "
                          "copies (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
+    ap.add_argument("--pmc-leg", default=None, help=argparse.SUPPRESS)      # internal: CONFIG:SPP:BAND:KERNEL, run under rocprofv3
     return ap.parse_args()
 
 
-def cpu_baseline(sample):
-    """The oracle on this host's cores, bounded sample of the same 10k-sphere scene (rank 0, N=1 only).
-
-    clean mode (thread pool = cores, no locks) renders WxH' with H' = max(H, 4*cores) rows so that every core
-    has rows to pull; faithful mode (one OS thread per row + a mutex per object, as scene.rs:151 / object.rs:50)
-    renders WxH."""
-    from oracle import rtx_oracle as oracle
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def make_objects(cfg):
     from rust_raytracing_amd import scenes
-    w, h, spp = (int(v) for v in sample.split("x"))
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    objs = scenes.random_spheres(N_SPHERES, 1)
-    sc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=spp, seed=scenes.RENDER_SEED)
-    out = {}
-    for mode, name, hh in ((oracle.MODE_CLEAN, "clean", max(h, 4 * cores)), (oracle.MODE_FAITHFUL, "faithful", h)):
-        t0 = time.perf_counter()
-        _, seg = oracle.render(sc, w, hh, n_threads=cores, mode=mode, want_segments=True)
-        dt = time.perf_counter() - t0
-        out[name] = (w * hh * spp / dt / 1e6, int(seg.sum()) / dt / 1e6, dt, w * hh * spp, hh)
-    best = max(out, key=lambda k: out[k][0])
-    return {
-        "value": out[best][0], "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": "same 10k-sphere scene, %dx%d px x %d spp (%d primary rays), f64 C restatement of the reference "
-                  "CPU path (the Rust crate cannot be built here), mode=%s" % (w, out[best][4], spp, out[best][3], best),
-        "clean_Mrays_s": out["clean"][0], "faithful_Mrays_s": out["faithful"][0],
-        "Msegments_s": out[best][1], "seconds": out["clean"][2] + out["faithful"][2],
-    }
+    if cfg["scene"] == "spheres":
+        return scenes.random_spheres(cfg["n"], cfg["seed"], box=cfg["box"])
+    return scenes.random_triangles(cfg["n"], cfg["seed"], box=cfg["box"])
 
 
 class Acc:
@@ -99,7 +113,7 @@ class Acc:
 
     def __init__(self):
         self.trace_ms = 0.0
-        self.segments = self.filter = self.exact = self.box = 0
+        self.segments = self.filter = self.exact = self.box = self.launches = 0
         self.kernel = 0
         self.n = 0
 
@@ -109,49 +123,248 @@ class Acc:
         self.filter += st.filter_tests
         self.exact += st.exact_tests
         self.box += st.box_tests
+        self.launches += st.trace_launches
         self.kernel = st.kernel
         self.n += 1
 
 
-def roofline_of(acc, traffic_key):
+def kernel_source_hash():
+    """Hash of the kernel sources: a counter file is only trusted for the tree it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rust-raytracing_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic(acc, cfg):
+    """What the kernel counted in this run, priced in lane-ops and bytes (unit = one ray segment)."""
     steps = max(acc.n, 1)
-    avg_ms = acc.trace_ms / steps
     seg = acc.segments / steps
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": KERNEL_NAMES.get(acc.kernel, str(acc.kernel)),
-           "avg_launch_ms": avg_ms, "segments_per_launch": seg}
-    if acc.kernel == 4:
+    tri = cfg["scene"] == "triangles"
+    out = {"segments_per_launch": seg / max(acc.launches / steps, 1)}
+    if acc.kernel in (4, 5):
         box, leaf, exact = acc.box / steps, (acc.filter - acc.box) / steps, acc.exact / steps
-        nbytes = box * 32.0 + leaf * 16.0 + exact * 32.0
-        out.update({"algorithmic_bytes_per_segment": nbytes / seg if seg else 0.0,
-                    "box_tests_per_segment": box / seg if seg else 0.0, "leaf_filter_tests_per_segment": leaf / seg if seg else 0.0,
-                    "exact_tests_per_segment": exact / seg if seg else 0.0,
-                    "note": "traversal bytes counted by the kernel (32 B per box test, 16 B per leaf filter record, 32 B per exact "
-                            "sphere test); node fetches are dependent L2/HBM reads: latency- and issue-bound, not bandwidth-bound"})
+        ops = box * LANE_OPS["box"] + leaf * LANE_OPS["tri_filter" if tri else "sphere_filter"] + \
+            exact * LANE_OPS["tri_exact" if tri else "sphere_exact"]
+        nbytes = box * 32.0 + leaf * (32.0 if tri else 16.0) + exact * (112.0 if tri else 32.0)
+        out.update({"box_tests_per_segment": box / seg if seg else 0.0, "leaf_filter_tests_per_segment": leaf / seg if seg else 0.0,
+                    "exact_tests_per_segment": exact / seg if seg else 0.0})
+    elif acc.kernel in (2, 3):
+        filt, exact = acc.filter / steps, acc.exact / steps
+        ops = filt * LANE_OPS["tri_filter" if tri else "sphere_filter"] + exact * LANE_OPS["tri_exact" if tri else "sphere_exact"]
+        nbytes = filt * (32.0 if tri else 16.0) + exact * (112.0 if tri else 32.0)
+        out.update({"filter_tests_per_segment": filt / seg if seg else 0.0, "exact_tests_per_segment": exact / seg if seg else 0.0})
     else:
-        nbytes = seg * N_SPHERES * 16.0
-        out.update({"algorithmic_bytes_per_segment": N_SPHERES * 16,
-                    "valu_frac": (acc.filter / steps * FILTER_OPS_PER_TEST) / (avg_ms * 1e-3) / VALU_LANE_OPS_PER_S
-                    if avg_ms > 0 and acc.filter else None,
-                    "note": "logical operand bandwidth (list is LDS/L2-resident by design; may exceed the HBM peak)"})
-    out["achieved"] = nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    out["frac"] = out["achieved"] / HBM_PEAK_GBS
-    out["traffic"] = None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
-        try:
-            rec = json.load(open(tj)).get(traffic_key)
-            out["traffic"] = rec["hbm_bytes_per_launch"] if rec else None
-        except Exception:
-            pass
-    # what the memory side actually moved (PMC, profiles/traffic.json) over this run's launch time: the "achieved HBM GB/s"
-    # of BASELINE.json's metric.  Far below `achieved`: the operands are served by LDS / L2, the kernels are VALU- and
-    # latency-bound
-    out["hbm_measured_gbs"] = out["traffic"] / (avg_ms * 1e-3) / 1e9 if out["traffic"] and avg_ms > 0 else None
+        exact = acc.exact / steps
+        ops = exact * LANE_OPS["tri_exact" if tri else "sphere_exact"]
+        nbytes = exact * (112.0 if tri else 32.0)
+    avg_ms = acc.trace_ms / steps
+    out.update({"lane_ops_per_step": ops, "bytes_per_step": nbytes, "bytes_per_segment": nbytes / seg if seg else 0.0,
+                "lane_ops_per_segment": ops / seg if seg else 0.0,
+                "Tlane_ops_per_s": ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                "frac_of_valu_peak": ops / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS if avg_ms > 0 else 0.0,
+                "operand_GBs": nbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                "note": "counted by the kernel in this run; operands are served by L2 / LDS, so operand_GBs is not an HBM rate"})
     return out
 
 
+def roofline_of(acc, cfg, counters, source):
+    """The roofline object of one measured kernel; `counters` = {counter: value per launch} or None."""
+    steps = max(acc.n, 1)
+    launches_per_step = max(acc.launches / steps, 1)
+    avg_ms = acc.trace_ms / max(acc.launches, 1)                  # average duration of ONE launch (hipEvents, launch stream)
+    out = {"bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "kernel": KERNEL_NAMES.get(acc.kernel, str(acc.kernel)),
+           "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+           "achieved": None, "frac": None, "lane_utilisation": None, "valu_busy": None, "effective_clock_ghz": None,
+           "traffic": None, "traffic_raw": None, "hbm_gbs": None, "hbm_frac": None,
+           "counters_source": source, "algorithmic": algorithmic(acc, cfg)}
+    c = counters or {}
+    t = avg_ms * 1e-3
+    if t > 0 and "SQ_THREAD_CYCLES_VALU" in c:
+        out["achieved"] = c["SQ_THREAD_CYCLES_VALU"] / t / 1e12
+        out["frac"] = out["achieved"] / VALU_PEAK_TLANEOPS
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            out["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+            # SIMD-cycles with a VALU instruction in flight (the counter ticks in units of 4 cycles) over 1024 SIMDs x launch time
+            out["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * t * 2.4e9)
+        out["valu_instructions_per_launch"] = c.get("SQ_INSTS_VALU")
+    if t > 0 and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports KB; MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> doubled
+        out["traffic_raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["fetch_bytes_corrected"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+        out["write_bytes"] = c["WRITE_SIZE"] * 1024.0
+        out["hbm_gbs"] = out["traffic"] / t / 1e9
+        out["hbm_frac"] = out["hbm_gbs"] / HBM_PEAK_GBS
+    if c.get("GRBM_GUI_ACTIVE") and c.get("_pmc_launch_s"):
+        out["effective_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / c["_pmc_launch_s"] / 1e9      # of the profiled pass
+    out["counters"] = {k: v for k, v in c.items()} if c else None          # per launch, as rocprofv3 reported them (sizes in KB)
+    if out["frac"] is None:
+        out["frac"] = out["algorithmic"]["frac_of_valu_peak"]
+        out["achieved"] = out["algorithmic"]["Tlane_ops_per_s"]
+        out["frac_source"] = "algorithmic model (no counters for this tree)"
+    else:
+        out["frac_source"] = "SQ_THREAD_CYCLES_VALU / launch time / peak"
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rocprofv3 counters, collected in this run
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_collect(leg, kernel_symbol, log):
+    """Runs `rocprofv3 --pmc ... -- python3 bench.py --pmc-leg LEG` once per counter pass; returns {counter: per launch}."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="rtx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    got = {}
+    try:
+        for name, counters in PMC_PASSES:
+            out_dir = os.path.join(tmp, name)
+            cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "--",
+                                               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-leg", leg]
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            log.append("pmc %s %s: rc %d, %.1f s" % (leg, name, p.returncode, time.perf_counter() - t0))
+            if p.returncode != 0:
+                return None, "rocprofv3 pass '%s' failed: %s" % (name, (p.stderr or p.stdout)[-300:])
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 pass '%s' wrote no counter file" % name
+            acc, cnt, dur = {}, {}, []
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if kernel_symbol not in r.get("Kernel_Name", ""):
+                        continue
+                    k = r["Counter_Name"]
+                    acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+                    cnt[k] = cnt.get(k, 0) + 1
+                    if "Start_Timestamp" in r and "End_Timestamp" in r and k == counters[0]:
+                        dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+            for k in counters:
+                if k in acc:
+                    got[k] = acc[k] / cnt[k]
+            if name == "fetch" and dur:
+                got["_pmc_launch_s"] = sum(dur) / len(dur)
+            if not any(k in acc for k in counters):
+                return None, "no rows of %s in pass '%s'" % (kernel_symbol, name)
+    except Exception as e:                                     # noqa: BLE001 -- a profiler problem must not fail the bench
+        return None, "rocprofv3: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return got, "rocprofv3 --pmc passes of this run (separate passes: %s)" % "; ".join(" ".join(c) for _, c in PMC_PASSES)
+
+
+def stored_counters(key):
+    """profiles/pmc_counters.json, trusted only for the kernel sources it was measured on."""
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    try:
+        d = json.load(open(path))
+    except Exception:                                          # noqa: BLE001
+        return None, "no counters: rocprofv3 was not run here and profiles/pmc_counters.json is absent"
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None, "no counters: profiles/pmc_counters.json was measured on other kernel sources (%s)" % d.get("kernel_source_hash")
+    rec = d.get("legs", {}).get(key)
+    if not rec:
+        return None, "no counters: profiles/pmc_counters.json has no leg %s" % key
+    return rec, "profiles/pmc_counters.json (kernel sources %s, %s)" % (d["kernel_source_hash"], d.get("collected", "?"))
+
+
+def counters_for(leg, kernel_symbol, allow_live, log):
+    if allow_live:
+        got, src = pmc_collect(leg, kernel_symbol, log)
+        if got:
+            return got, src
+        log.append("live counters unavailable: " + src)
+    return stored_counters(leg)
+
+
+def pmc_leg(spec):
+    """Child mode (under rocprofv3): the workload of one leg, one warm-up render and one measured-shape render."""
+    import torch
+    import rust_raytracing_amd as rtx
+    from rust_raytracing_amd import scenes, tiles
+    name, spp, band, kernel = spec.split(":")
+    cfg = CONFIGS[name]
+    world = 8 if band == "band" else 1
+    objs = make_objects(cfg)
+    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=int(spp), seed=scenes.RENDER_SEED, kernel=int(kernel)),
+                                rtx.Camera(*scenes.CAMERA), objs).upload(0)
+    rb, rs, n_rows = tiles.rows_for_rank(cfg["h"], 0, world)
+    buf = tiles.alloc_band(cfg["h"], cfg["w"], world, torch.device("cuda", 0))
+    for _ in range(2):
+        hnd.render_rows(cfg["w"], cfg["h"], rb, rs, n_rows, buf.data_ptr())
+    torch.cuda.synchronize()
+    hnd.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(seconds):
+    """The oracle on this host's cores, on a sub-sample of the benchmark's OWN view: pixels (x, y) = (kx*i, ky*j) of the
+    1920x1080 C2 frame through rtxo_render_pixels (clean mode: thread pool = cores, no locks), and whole rows of the same
+    frame in the reference's threading (faithful mode: one OS thread per row, a mutex per object; scene.rs:151,
+    object.rs:50).  The sample is sized from a pilot so that each mode takes about `seconds`."""
+    import numpy as np
+    from oracle import rtx_oracle as oracle
+    from rust_raytracing_amd import scenes
+    cfg = CONFIGS["C2"]
+    w, h = cfg["w"], cfg["h"]
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    objs = make_objects(cfg)
+    sc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=1, seed=scenes.RENDER_SEED)
+
+    def grid(n_target):
+        k = max(1, int(round((w * h / max(n_target, 1)) ** 0.5)))
+        xs, ys = np.meshgrid(np.arange(k // 2, w, k), np.arange(k // 2, h, k))
+        return xs.ravel().astype(np.uint32), ys.ravel().astype(np.uint32), k
+
+    xs, ys, _ = grid(64 * cores)                                         # pilot
+    t0 = time.perf_counter()
+    oracle.render_pixels(sc, w, h, xs, ys, n_threads=cores)
+    pilot = len(xs) / max(time.perf_counter() - t0, 1e-6)
+    xs, ys, k = grid(min(pilot * seconds, w * h / 4))
+    t0 = time.perf_counter()
+    _, seg = oracle.render_pixels(sc, w, h, xs, ys, n_threads=cores, want_segments=True)
+    dt = time.perf_counter() - t0
+    clean = (len(xs) / dt / 1e6, int(seg.sum()) / dt / 1e6, dt, len(xs), int(seg.sum()))
+    # faithful: whole rows of the same frame, as many as ~seconds allow at ~1/8 of the clean rate (measured ratio round 1)
+    n_rows = int(min(max(clean[0] * 1e6 / 8.0 * seconds / w, 1), h // 2))
+    stride = h // n_rows
+    t0 = time.perf_counter()
+    _, fseg = oracle.render(sc, w, h, n_threads=cores, mode=oracle.MODE_FAITHFUL, row_begin=stride // 2, row_stride=stride,
+                            want_segments=True)
+    fdt = time.perf_counter() - t0
+    f_rows = len(range(stride // 2, h, stride))
+    faithful = (f_rows * w / fdt / 1e6, int(fseg.sum()) / fdt / 1e6, fdt, f_rows * w)
+    return {
+        "value": clean[0], "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": "the benchmark's own view: every %dth row and column of the 1920x1080 C2 frame (%d pixels x 1 spp, %.2f "
+                  "segments per ray) through the f64 C restatement of the reference CPU path (the Rust crate cannot be built "
+                  "here), clean mode: %d threads, no locks" % (k, clean[3], clean[4] / max(clean[3], 1), cores),
+        "Msegments_s": clean[1], "segments_per_primary_ray": clean[4] / max(clean[3], 1), "seconds": clean[2] + fdt,
+        "clean_Mrays_s": clean[0], "faithful_Mrays_s": faithful[0], "faithful_Msegments_s": faithful[1],
+        "faithful_sample": "%d whole rows of the same frame (%d rays), one OS thread per row + a mutex per object "
+                           "(scene.rs:151, object.rs:50)" % (f_rows, faithful[3]),
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.pmc_leg:
+        return pmc_leg(args.pmc_leg)
+    import torch                       # first: one HIP runtime for torch tensors and librtx_hip
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,31 +388,31 @@ def main():
     import rust_raytracing_amd as rtx
     from rust_raytracing_amd import scenes, tiles
 
-    spp_per_gpu = args.spp if args.spp is not None else SPP_PER_GPU
-    spp = spp_per_gpu * world                                  # weak scaling: fixed rays per GPU
-    objs = scenes.random_spheres(N_SPHERES, 1)
-    cfg = rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=args.kernel)
-    scene = rtx.Scene.from_packed(cfg, rtx.Camera(*scenes.CAMERA), objs)
-    handle = scene.upload(dev_index)                           # scene resident in HBM before the timed region
-    rb, rs, n_rows = tiles.rows_for_rank(HEIGHT, rank, world)
-    band = tiles.alloc_band(HEIGHT, WIDTH, world, dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        st = handle.render_rows(WIDTH, HEIGHT, rb, rs, n_rows, band.data_ptr(), stream=stream)
-        if rehearse:
-            torch.cuda.synchronize(dev)
-            full = tiles.gather_bands(band.cpu(), HEIGHT, WIDTH, rank, world, dst=0)
-        else:
-            full = tiles.gather_bands(band, HEIGHT, WIDTH, rank, world, dst=0)
-        return st, full
+    cfg = CONFIGS[args.config]
+    W, H = cfg["w"], cfg["h"]
+    spp_named = args.spp if args.spp is not None else cfg["spp"]
+    spp = spp_named * world if args.weak else spp_named           # strong scaling (default): the frame is the same for every N
+    log = []
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(n_warm, n_steps):
+    def run(handle, w, h, rk, wd, n_warm, n_steps, gather):
+        rb, rs, n_rows = tiles.rows_for_rank(h, rk, wd)
+        band = tiles.alloc_band(h, w, wd, dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def step():
+            st = handle.render_rows(w, h, rb, rs, n_rows, band.data_ptr(), stream=stream)
+            if not gather:
+                return st, band[:n_rows]
+            if rehearse:
+                torch.cuda.synchronize(dev)
+                return st, tiles.gather_bands(band.cpu(), h, w, rank, world, dst=0)
+            return st, tiles.gather_bands(band, h, w, rank, world, dst=0)
+
         for _ in range(n_warm):
             step()
         fence()
@@ -209,9 +422,12 @@ def main():
             st, full = step()
             acc.add(st)
         fence()
-        return time.perf_counter() - t0, acc, full
+        return time.perf_counter() - t0, acc, full, n_rows
 
-    elapsed, acc, full = timed(args.warmup, args.steps)
+    objs = make_objects(cfg)
+    rcfg = rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=args.kernel)
+    handle = rtx.Scene.from_packed(rcfg, rtx.Camera(*scenes.CAMERA), objs).upload(dev_index)   # resident before the timed region
+    elapsed, acc, full, _ = run(handle, W, H, rank, world, args.warmup, args.steps, gather=True)
     if world > 1:
         t = torch.tensor([elapsed, float(acc.segments)], dtype=torch.float64, device="cpu" if rehearse else dev)
         tmax = t.clone()
@@ -223,43 +439,84 @@ def main():
     else:
         total_segments = acc.segments
 
+    single = world == 1 and args.steps > 0
+    live_pmc = single and not args.no_pmc
     lds = None
-    if world == 1 and not args.no_lds_sweep and acc.kernel != 2 and args.steps > 0:
-        handle.set_config(cfg.with_kernel(rtx.RTX_KERNEL_MIXED))
-        e2, acc2, full2 = timed(1, 2)
-        lds = {"value": WIDTH * HEIGHT * spp * 2 / e2 / 1e6, "unit": "Mrays/s", "ms_per_step": e2 / 2 * 1e3,
+    if single and args.config == "C2" and not args.no_lds_sweep and acc.kernel != 2:
+        handle.set_config(rcfg.with_kernel(rtx.RTX_KERNEL_MIXED))
+        e2, acc2, full2, _ = run(handle, W, H, 0, 1, 1, 2, gather=False)
+        c2, src2 = counters_for("C2:%d:full:2" % spp, KERNEL_SYMBOL[2], live_pmc, log)
+        lds = {"value": W * H * spp * 2 / e2 / 1e6, "unit": "Mrays/s", "ms_per_step": e2 / 2 * 1e3,
                "image_identical_to_value_kernel": bool(torch.equal(full, full2)) if full is not None else None,
-               "roofline": roofline_of(acc2, "c2_%dspp_kernel2" % spp_per_gpu)}
-        handle.set_config(cfg)
+               "roofline": roofline_of(acc2, cfg, c2, src2)}
+        handle.set_config(rcfg)
+    image_mean = float(full.mean()) if full is not None else float("nan")
+    handle.close()
+    del full
+
+    others = None
+    if single and args.config == "C2" and not args.no_other_configs:
+        other_spp = dict(kv.split("=") for kv in args.other_spp.split(","))
+        others = []
+        for name, band in (("C3", False), ("C4", True), ("C5", True)):
+            oc = CONFIGS[name]
+            s = int(other_spp.get(name, 4))
+            o_objs = objs if oc["scene"] == cfg["scene"] and oc["n"] == cfg["n"] and oc["seed"] == cfg["seed"] else make_objects(oc)
+            t_up = time.perf_counter()
+            hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=s, seed=scenes.RENDER_SEED), rtx.Camera(*scenes.CAMERA), o_objs).upload(0)
+            t_up = time.perf_counter() - t_up
+            wd = 8 if band else 1
+            e, a, img, n_rows = run(hnd, oc["w"], oc["h"], 0, wd, 1, 2, gather=False)
+            hnd.close()
+            rays = n_rows * oc["w"] * s * 2
+            leg = "%s:%d:%s:0" % (name, s, "band" if band else "full")
+            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, "trace_"), live_pmc and name in ("C3", "C5"), log)
+            others.append({
+                "config": name, "workload": "%s, %s at %d spp (the config names %d spp; Mrays/s is a rate)" % (
+                    oc["name"], "the interleaved row band rank 0 of 8 owns (%d rows)" % n_rows if band else "full frame", s, oc["spp"]),
+                "value": rays / e / 1e6, "unit": "Mrays/s", "ms_per_step": e / 2 * 1e3,
+                "Msegments_per_s": a.segments / e / 1e6, "segments_per_primary_ray": a.segments / rays,
+                "scene_upload_s": t_up, "image_mean": float(img.mean()), "roofline": roofline_of(a, oc, cnt, src)})
+            del img, o_objs
 
     if rank == 0:
         steps = max(args.steps, 1)
-        rays_per_step = WIDTH * HEIGHT * spp
+        rays_per_step = W * H * spp
         value = rays_per_step * args.steps / elapsed / 1e6 if args.steps else 0.0
+        cnt, src = (counters_for("%s:%d:full:%d" % (args.config, spp, args.kernel), KERNEL_SYMBOL.get(acc.kernel, "trace_"), live_pmc, log)
+                    if world == 1 else (None, "counters are collected at N = 1 only"))
+        roof = roofline_of(acc, cfg, cnt, src)
         line = {
-            "metric": "Mrays/s (primary rays, whole node), 10k-sphere 1080p 64spp",
+            "metric": "Mrays/s (primary rays, whole node), %s %dspp%s" % (
+                "10k-sphere 1080p" if args.config in ("C2",) else args.config, spp_named, " per GPU (weak scaling)" if args.weak else ""),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             **({"rehearsal": "all ranks on cuda:0, gloo gather through host memory: not a measurement"} if rehearse else {}),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: 10k random spheres (scene seed 1), 1920x1080, %d spp per GPU (%d total), "
-                                   "max_bounces 10, render seed 42" % (spp_per_gpu, spp),
-                       "width": WIDTH, "height": HEIGHT, "rays_per_pixel": spp, "n_spheres": N_SPHERES,
-                       "partition": "interleaved row bands, 1 gather" if world > 1 else "single GPU",
+            "config": {"workload": "%s: %s, %d rays per pixel in total, max_bounces 10, render seed 42" % (args.config, cfg["name"], spp),
+                       "width": W, "height": H, "rays_per_pixel": spp, "n_objects": cfg["n"],
+                       "partition": "interleaved row bands (rank r renders rows r, r + %d, ...), one gather to rank 0 inside the timed region" % world
+                       if world > 1 else "single GPU",
                        "kernel": KERNEL_NAMES.get(acc.kernel, str(acc.kernel))},
-            "Msegments_per_s": total_segments / elapsed / 1e6,
+            "Msegments_per_s": total_segments / elapsed / 1e6 if elapsed > 0 else 0.0,
             "segments_per_primary_ray": total_segments / (rays_per_step * steps),
-            "image_mean": float(full.mean()) if full is not None else float("nan"),
-            "roofline": roofline_of(acc, "c2_%dspp_kernel%d" % (spp_per_gpu, acc.kernel)),
+            "image_mean": image_mean,
+            "hbm_gbs": roof["hbm_gbs"],
+            "roofline": roof,
         }
         if lds is not None:
             line["lds_sweep"] = lds
+        if others is not None:
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_sample)
+            cb = cpu_baseline(args.cpu_seconds)
             line["cpu_baseline"] = cb
-            line["speedup_vs_cpu"] = value / cb["value"] if cb["value"] > 0 else None
+            line["speedup_vs_cpu"] = {"primary_rays": value / cb["value"] if cb["value"] > 0 else None,
+                                      "segments": line["Msegments_per_s"] / cb["Msegments_s"] if cb["Msegments_s"] > 0 else None,
+                                      "primary_rays_vs_faithful": value / cb["faithful_Mrays_s"] if cb["faithful_Mrays_s"] > 0 else None}
+        if log:
+            line["log"] = log
         print(json.dumps(line), flush=True)
-    handle.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -308,3 +308,42 @@ def test_bvh_invariants_on_awkward_and_random_scenes(rtx):
     deep = _host_scene(rtx, scenes.random_triangles(600000, 2))                   # deep enough for the HBM stack spill variant
     assert deep["stack_bound"] > 30 and deep["tri_leaf_entries"] == deep["tri_in_tree"]
 
+
+
+def test_bench_roofline_object_is_a_fraction_of_a_real_ceiling(tmp_path, monkeypatch):
+    """bench.py's roofline arithmetic on synthetic counts (no GPU): frac = lane-ops issued / launch time / VALU peak,
+    hbm_frac = (2 x FETCH + WRITE) / launch time / 8 TB/s, both <= 1 for round 1's measured counters; a counter file is
+    refused when it was measured on other kernel sources."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    acc = b.Acc()
+
+    class St:                                   # round 1, C2 at 64 spp, one launch of trace_bvh_kernel<false,false>
+        trace_ms = 94.78; segments = 280450000; filter_tests = int(280450000 * 97.6); exact_tests = int(280450000 * 1.2)
+        box_tests = int(280450000 * 96.0); trace_launches = 1; kernel = 4
+    acc.add(St)
+    counters = {"SQ_THREAD_CYCLES_VALU": 1.639e11 * 8, "SQ_ACTIVE_INST_VALU": 5.557e9 * 8, "SQ_INSTS_VALU": 5.474e9 * 8,
+                "FETCH_SIZE": 13218599.7, "WRITE_SIZE": 9146993.3}
+    r = b.roofline_of(acc, b.CONFIGS["C2"], counters, "test")
+    assert r["bound"] == "valu" and 0.1 < r["frac"] < 0.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["lane_utilisation"] - 0.46) < 0.01 and 0.5 < r["valu_busy"] < 1.0
+    assert abs(r["traffic"] - (2 * 13218599.7 + 9146993.3) * 1024) < 1 and 0.03 < r["hbm_frac"] < 0.06
+    assert 0 < r["algorithmic"]["frac_of_valu_peak"] < r["frac"]          # the minimal op count is below what was issued
+    assert abs(r["algorithmic"]["bytes_per_segment"] - (96 * 32 + 1.6 * 16 + 1.2 * 32)) < 1.0
+    r0 = b.roofline_of(acc, b.CONFIGS["C2"], None, "none")
+    assert r0["traffic"] is None and r0["hbm_frac"] is None and 0 < r0["frac"] <= 1 and "algorithmic" in r0["frac_source"]
+    # stored counters: refused for other sources, accepted for this tree
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "rust-raytracing_amd" / "csrc")
+    (tmp_path / "rust-raytracing_amd" / "csrc" / "k.hip").write_text("kernel v1")
+    json.dump({"kernel_source_hash": b.kernel_source_hash(), "collected": "t", "legs": {"C2:64:full:0": counters}},
+              open(tmp_path / "profiles" / "pmc_counters.json", "w"))
+    got, src = b.stored_counters("C2:64:full:0")
+    assert got == counters and "pmc_counters.json" in src
+    (tmp_path / "rust-raytracing_amd" / "csrc" / "k.hip").write_text("kernel v2")
+    got, src = b.stored_counters("C2:64:full:0")
+    assert got is None and "other kernel sources" in src

@@ -772,51 +772,88 @@ def test_c2_full_size_properties(gpu, oracle):
     assert a.mean() > 0.01
 
 
-def test_bench_line_contract(gpu):
-    """bench.py at a reduced sample count: one JSON line with the contract's keys, the roofline and cpu_baseline objects,
-    and the two kernels' frames bit-identical."""
+def _bench(args, timeout=900, launcher=None, env=None):
     import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--spp", "2",
-                          "--cpu-sample", "48x16x1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_roofline(r):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "counters_source", "algorithmic", "avg_launch_ms"):
+        assert key in r, key
+    assert r["bound"] == "valu" and abs(r["peak"] - 78.6432) < 1e-3 and r["unit"] == "Tlane-op/s"
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9        # a fraction of a real ceiling
+    assert 0.0 < r["algorithmic"]["frac_of_valu_peak"] <= 1.0
+    if r["traffic"] is not None:
+        assert 0.0 < r["hbm_frac"] <= 1.0 and r["traffic"] >= r["traffic_raw"] > 0
+        assert abs(r["hbm_gbs"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["hbm_gbs"]
+
+
+def test_bench_line_contract(gpu):
+    """bench.py at a reduced sample count (counters off: they are the next test): one JSON line with the contract's keys,
+    strong scaling by default, roofline objects that are fractions of a real ceiling for the value kernel, the LDS sweep
+    and the three other configs, a cpu_baseline on the benchmark's own view, and the two kernels' frames bit-identical."""
+    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C4=2,C5=1", "--no-pmc"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs", "lds_sweep"):
         assert key in d, key
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and d["value"] > 0
-    r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert key in r, key
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["scaling"] == "strong" and "10k-sphere 1080p" in d["metric"]
+    assert "workload" in d["config"] and d["config"]["rays_per_pixel"] == 2 and d["value"] > 0
+    _check_roofline(d["roofline"])
+    assert d["roofline"]["traffic"] is None or "profiles/pmc_counters.json" in d["roofline"]["counters_source"]
     c = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "Msegments_s", "faithful_Mrays_s"):
         assert key in c, key
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    # the CPU leg samples the GPU's own view: same segments per primary ray up to sampling noise
+    assert abs(c["segments_per_primary_ray"] - d["segments_per_primary_ray"]) < 0.35
+    assert d["speedup_vs_cpu"]["primary_rays"] > 100 and d["speedup_vs_cpu"]["segments"] > 100
     assert d["lds_sweep"]["image_identical_to_value_kernel"] is True
+    _check_roofline(d["lds_sweep"]["roofline"])
+    assert [o["config"] for o in d["other_configs"]] == ["C3", "C4", "C5"]
+    for o in d["other_configs"]:
+        assert o["value"] > 0 and o["Msegments_per_s"] > 0 and 1.0 <= o["segments_per_primary_ray"] <= 11.0
+        _check_roofline(o["roofline"])
+
+
+def test_bench_collects_counters_in_the_run(gpu):
+    """With rocprofv3 on the PATH the roofline's counters come from this very run (child passes under rocprofv3 --pmc):
+    lane-ops issued vs the VALU ceiling, HBM-side bytes vs 8 TB/s -- both fractions below 1."""
+    import shutil
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("rocprofv3 not installed")
+    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--no-cpu-baseline", "--no-lds-sweep", "--no-other-configs"])
+    r = d["roofline"]
+    assert "of this run" in r["counters_source"], (r["counters_source"], d.get("log"))
+    _check_roofline(r)
+    assert r["frac_source"].startswith("SQ_THREAD_CYCLES_VALU") and 0.0 < r["lane_utilisation"] <= 1.0
+    assert r["traffic"] > 1920 * 1080 * 2 * 24            # at least the sample planes were written
+    assert d["hbm_gbs"] == r["hbm_gbs"]
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
     """The N = 2 path of bench.py with both ranks on this box's one GPU (gloo gather through host copies, because RCCL
-    refuses two ranks on one device): launch line, row partition, per-rank render, gather, de-interleave, max-over-ranks
-    timing -- and the assembled 2 x 2 spp frame has the mean of a single-rank 4 spp frame (same pixels, same samples)."""
+    refuses two ranks on one device): launch line, STRONG-scaling row partition of the same 4-spp frame, per-rank render,
+    gather inside the timed region, de-interleave, max-over-ranks timing -- the assembled frame is the single-rank frame
+    (same pixels, same samples), and so is the segment count."""
     import sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "1", "--warmup", "0", "--spp", "2", "--no-cpu-baseline", "--no-lds-sweep"]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + common,
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert two.returncode == 0, two.stderr[-3000:]
-    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, two.stdout[-2000:]
-    d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["config"]["rays_per_pixel"] == 4 and "rehearsal" in d2
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--spp", "4",
-                          "--no-cpu-baseline", "--no-lds-sweep"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert one.returncode == 0, one.stderr[-2000:]
-    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    common = ["--steps", "1", "--warmup", "0", "--spp", "4", "--no-cpu-baseline", "--no-lds-sweep", "--no-other-configs", "--no-pmc"]
+    d2 = _bench(["--gpus", "2", "--rehearse-on-one-gpu"] + common, env=env,
+                launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29653"])
+    assert d2["n_gpus"] == 2 and d2["config"]["rays_per_pixel"] == 4 and "rehearsal" in d2 and d2["scaling"] == "strong"
+    d1 = _bench(common)
+    assert d1["config"]["rays_per_pixel"] == 4 and d1["metric"] == d2["metric"]
     # (the means are reduced on different devices -- host copy vs GPU tensor -- so they may differ in the last bits)
     assert abs(d1["image_mean"] - d2["image_mean"]) <= 1e-12 and d1["segments_per_primary_ray"] == d2["segments_per_primary_ray"]
-
+    dw = _bench(["--gpus", "2", "--rehearse-on-one-gpu", "--weak"] + common[:4] + ["--spp", "2"] + common[6:], env=env,
+                launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29654"])
+    assert dw["scaling"] == "weak" and dw["config"]["rays_per_pixel"] == 4 and "weak" in dw["metric"]
+    assert abs(dw["image_mean"] - d1["image_mean"]) <= 1e-12

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Copies what tools/gpu_profile.sh left under gpurun_out/<tag>/ into profiles/ (tracked): the bench line, the rocprofv3
+kernel-trace summary of the same command, and profiles/pmc_counters.json = the per-launch counters of that bench run
+stamped with the hash of the kernel sources they were measured on (bench.py falls back to it when rocprofv3 is absent).
+
+    python tools/store_profiles.py r02
+"""
+import glob
+import importlib.util
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+G = os.path.join(ROOT, "gpurun_out", tag)
+P = os.path.join(ROOT, "profiles")
+
+spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+line = json.load(open(os.path.join(G, "bench_n1.json")))
+shutil.copy(os.path.join(G, "bench_n1.json"), os.path.join(P, "%s_bench_n1.json" % tag))
+stats = max(glob.glob(os.path.join(G, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+shutil.copy(stats, os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
+
+legs = {}
+spp = line["config"]["rays_per_pixel"]
+if line["roofline"].get("counters"):
+    legs["C2:%d:full:0" % spp] = line["roofline"]["counters"]
+if line.get("lds_sweep", {}).get("roofline", {}).get("counters"):
+    legs["C2:%d:full:2" % spp] = line["lds_sweep"]["roofline"]["counters"]
+for o in line.get("other_configs", []):
+    if o["roofline"].get("counters"):
+        s = int(o["workload"].split(" at ")[1].split(" spp")[0])
+        legs["%s:%d:%s:0" % (o["config"], s, "band" if "band" in o["workload"] else "full")] = o["roofline"]["counters"]
+json.dump({"kernel_source_hash": bench.kernel_source_hash(), "collected": "%s, %s" % (tag, time.strftime("%Y-%m-%d")),
+           "note": "per launch, as rocprofv3 reported them (FETCH_SIZE / WRITE_SIZE in KB); passes: " +
+                   "; ".join(" ".join(c) for _, c in bench.PMC_PASSES), "legs": legs},
+          open(os.path.join(P, "pmc_counters.json"), "w"), indent=1)
+print("stored", sorted(legs), "kernel sources", bench.kernel_source_hash())
+for l in open(stats).read().splitlines()[:6]:
+    print(l[:220])
