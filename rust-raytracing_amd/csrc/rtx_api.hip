@@ -181,6 +181,7 @@ struct PackedScene {
     std::vector<MaterialX> mats;
     std::vector<float4> sph32, tri32, leaf32;
     std::vector<uint32_t> tri_fidx;
+    std::vector<uint8_t> tri_rec_free_axis;          // per tree record (leaf order): the axis its footprint is unbounded along
     BvhBuild bvh;
     Bvh4Build bvh4;
 };
@@ -244,11 +245,16 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
         sph32[k] = make_float4(fx[k], fx[k + 1], fy[k], fy[k + 1]);
         sph32[k + 1] = make_float4(fz[k], fz[k + 1], fw[k], fw[k + 1]);
     }
-    // triangle filter records (rtx_device.h "triangle filter"): only triangles that can be hit at all.  The "plain"
-    // ones (pivot rows x, y; well-conditioned projection) also get a footprint box for the tree (rtx_bvh.h).
+    // triangle filter records (rtx_device.h "triangle filter"): only triangles that can be hit at all.  Triangle::contains
+    // decides a hit from two coordinates of the hit point -- rows (i, j) of its elimination: (x, y) unless a zero pivot
+    // swaps another row in (triangle.rs:60-71,81-87; e.g. every face in a plane x = const is solved in (y, z)) -- so the
+    // triangle enters the tree with its footprint in THAT coordinate plane, unbounded along the third axis (rtx_bvh.h).
+    // Triangles solved in (x, y) also get a real filter record; the others a pass-all record (their leaf box already
+    // says "the ray passes over the footprint").  An ill-conditioned projection (the rounding of a, b could report a
+    // hit outside the footprint) keeps a triangle outside the tree: tested for every segment.
     struct TriRec { float4 A, B; uint32_t tri; };
-    std::vector<TriRec> plain_recs, always_recs;
-    std::vector<BvhBox> tri_boxes;
+    std::vector<TriRec> tree_recs[3], always_recs;                     // tree_recs[f]: the elimination does not read axis f
+    std::vector<BvhBox> tri_boxes[3];
     double tri_extent = 0.0;
     for (size_t k = 0; k < tris.size(); ++k) {
         const TriX &t = tris[k];
@@ -261,17 +267,18 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
         double v[3][3];
         bool finite = true;
         for (int c = 0; c < 9; ++c) { v[c / 3][c % 3] = o.geom[c] - centre[c % 3]; finite = finite && std::isfinite(o.geom[c]); }
-        const double rx = v[1][0] - v[0][0], ry = v[1][1] - v[0][1], sx = v[2][0] - v[0][0], sy = v[2][1] - v[0][1];
-        const double det = rx * sy - ry * sx;
-        const bool rows_xy = (t.i == 0 && t.j == 1);
+        const int free_axis = 3 - (int)t.i - (int)t.j;                // t.i != t.j: the two rows the elimination reads
+        const int a0 = free_axis == 0 ? 1 : 0, a1 = free_axis == 2 ? 1 : 2;
+        const double r0 = v[1][a0] - v[0][a0], r1 = v[1][a1] - v[0][a1], s0 = v[2][a0] - v[0][a0], s1 = v[2][a1] - v[0][a1];
+        const double det = r0 * s1 - r1 * s0;
         BvhBox fp;
-        const bool plain = finite && rows_xy && std::fabs(det) > 1e-6 * std::hypot(rx, ry) * std::hypot(sx, sy) &&
-                           triangle_footprint(o.geom, fp);
+        const bool in_tree = finite && t.i != t.j && std::fabs(det) > 1e-6 * std::hypot(r0, r1) * std::hypot(s0, s1) &&
+                             triangle_footprint(o.geom, fp, free_axis);
         TriRec rec;
         rec.A = make_float4(0.f, 0.f, 0.f, 0.f);                       // "always a candidate"
         rec.B = make_float4(0.f, 0.f, 0.f, 0.f);
         rec.tri = (uint32_t)k;
-        if (plain) {
+        if (in_tree && free_axis == 2) {
             const double xlo = std::fmin(v[0][0], std::fmin(v[1][0], v[2][0])), xhi = std::fmax(v[0][0], std::fmax(v[1][0], v[2][0]));
             const double ylo = std::fmin(v[0][1], std::fmin(v[1][1], v[2][1])), yhi = std::fmax(v[0][1], std::fmax(v[1][1], v[2][1]));
             const double kc = t.n.x * v[0][0] + t.n.y * v[0][1] + t.n.z * v[0][2];
@@ -280,36 +287,54 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
             rec.B = make_float4((float)(0.5 * (xlo + xhi)), (float)(0.5 * (ylo + yhi)),
                                 round_up_f32(0.5 * (xhi - xlo) * grow + 1e-30), round_up_f32(0.5 * (yhi - ylo) * grow + 1e-30));
             for (int c = 0; c < 9; ++c) tri_extent = std::fmax(tri_extent, std::fabs(v[c / 3][c % 3]));
-            plain_recs.push_back(rec);
-            tri_boxes.push_back(fp);
-        } else {
-            always_recs.push_back(rec);
         }
+        if (in_tree) { tree_recs[free_axis].push_back(rec); tri_boxes[free_axis].push_back(fp); }
+        else always_recs.push_back(rec);
     }
+    // a plane with fewer than 5 triangles gets no sub-tree: those are tested for every segment ((x, y) ones keep their
+    // filter record, which is valid outside the tree too)
+    std::vector<TriRec> demoted;
+    for (int f = 0; f < 3; ++f)
+        if (tree_recs[f].size() <= 4) {
+            for (const TriRec &r : tree_recs[f]) (f == 2 ? demoted : always_recs).push_back(r);
+            tree_recs[f].clear(); tri_boxes[f].clear();
+        }
 
-    // flat BVH over the sphere boxes and the plain triangles' footprints (rtx_bvh.h); a kind with fewer than 5
-    // members, or non-finite spheres, gets no sub-tree (the BVH kernel then tests those shapes for every segment)
+    // flat BVH over the sphere boxes and the triangle footprints (rtx_bvh.h); fewer than 5 spheres, or non-finite
+    // spheres, get no sub-tree (the BVH kernel then tests those shapes for every segment)
     std::vector<BvhBox> sphere_boxes(spheres.size());
     bool spheres_finite = true;
     for (size_t k = 0; k < spheres.size() && spheres_finite; ++k)
         spheres_finite = sphere_box(scene->objects[sphere_id[k]].geom, sphere_boxes[k]);
-    if (!spheres_finite) sphere_boxes.clear();
+    if (!spheres_finite || sphere_boxes.size() <= 4) sphere_boxes.clear();
     static const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
     BvhBuild &bvh = p.bvh;
     bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(), use_sah);
     Bvh4Build &bvh4 = p.bvh4;
     bvh4 = collapse_to_bvh4(bvh);
 
-    // records in leaf order first (a triangle leaf's link indexes them), then the always-candidates
+    // records in leaf order first (a triangle leaf's link indexes them; tri_order indexes [plane xy][xz][yz]), then the
+    // ones outside the tree
     std::vector<float4> &tri32 = p.tri32;
     std::vector<uint32_t> &tri_fidx = p.tri_fidx;
-    tri32.reserve(2 * (plain_recs.size() + always_recs.size()));
+    std::vector<TriRec> all_tree;
+    std::vector<uint8_t> all_free;
+    for (int f = 2; f >= 0; --f)
+        for (const TriRec &r : tree_recs[f]) { all_tree.push_back(r); all_free.push_back((uint8_t)f); }
+    tri32.reserve(2 * (all_tree.size() + demoted.size() + always_recs.size()) + 2);
+    p.tri_rec_free_axis.clear();
+    size_t n_in_tree = 0;
     if (bvh.has_tris) {
-        for (uint32_t idx : bvh.tri_order) { const TriRec &r = plain_recs[idx]; tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
-    } else {
-        for (const TriRec &r : plain_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
+        for (uint32_t idx : bvh.tri_order) {
+            const TriRec &r = all_tree[idx];
+            tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); p.tri_rec_free_axis.push_back(all_free[idx]);
+        }
+        n_in_tree = bvh.tri_order.size();
+    } else {                                    // (the build was refused: coordinates too large for the f32 slab test)
+        for (size_t k = 0; k < all_tree.size(); ++k) (all_free[k] == 2 ? demoted : always_recs).push_back(all_tree[k]);
     }
-    p.sv.n_tri_tree = bvh.has_tris ? (uint32_t)plain_recs.size() : 0u;
+    p.sv.n_tri_tree = (uint32_t)n_in_tree;
+    for (const TriRec &r : demoted) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
     for (const TriRec &r : always_recs) { tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); }
     if (!tri32.empty()) {                       // one pad record: bvh_step reads records in pairs
         tri32.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
@@ -331,8 +356,9 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     p.sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
     p.sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);
     if (std::getenv("RTX_HIP_DEBUG"))
-        std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree, %zu always tested), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
-                     spheres.size(), tris.size(), plain_recs.size(), always_recs.size(), bvh.nodes.size(), bvh4.nodes.size(), bvh4.depth);
+        std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree: %zu xy / %zu xz / %zu yz footprints, %zu tested per segment), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
+                     spheres.size(), tris.size(), n_in_tree, tree_recs[2].size(), tree_recs[1].size(), tree_recs[0].size(),
+                     demoted.size() + always_recs.size(), bvh.nodes.size(), bvh4.nodes.size(), bvh4.depth);
     std::vector<float4> &leaf32 = p.leaf32;
     leaf32.assign(bvh.prims.size(), make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t k = 0; k < bvh.prims.size(); ++k) {
@@ -601,13 +627,6 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         }
         return RTX_OK;
     }
-    // samples per launch: all of them unless the sample planes would exceed the scratch cap
-    uint64_t batch = spp;
-    {
-        const uint64_t per_sample = (uint64_t)npix * 3 * sizeof(double);
-        const uint64_t fit = scratch_cap_bytes() / per_sample;
-        if (batch > fit) batch = fit ? fit : 1;
-    }
     // AUTO: a BVH kernel when a tree was built at upload and few shapes stay outside it (those are tested for every
     // segment in f64), else the LDS sweep with its sphere and triangle filters.  Which BVH kernel: lock-step waves for
     // sphere scenes; the regrouping schedule when the tree holds a triangle mesh (measured, regroup vs lock-step:
@@ -622,6 +641,22 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         } else {
             kernel = RTX_KERNEL_MIXED;
         }
+    }
+
+    // the BVH kernels' ray queue runs over 8x8 pixel tiles (a wave's 64 rays = one tile); a sample then has
+    // tiles_x * tiles_y * 64 queue slots (the padding of partial tiles included), else npix
+    const bool tiled = (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) && !std::getenv("RTX_HIP_NO_TILES");
+    const uint32_t tiles_x = tiled ? (width + 7u) / 8u : 0u;
+    const uint64_t per_sample64 = tiled ? (uint64_t)tiles_x * ((n_rows + 7u) / 8u) * 64u : (uint64_t)npix;
+    if (per_sample64 > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: more than 2^32 ray slots per sample");
+    const uint32_t per_sample = (uint32_t)per_sample64;
+    // samples per launch: all of them unless the sample planes would exceed the scratch cap (or 2^32 rays)
+    uint64_t batch = spp;
+    {
+        const uint64_t fit = scratch_cap_bytes() / (per_sample64 * 4 * sizeof(double));
+        const uint64_t fit32 = 0xFFFFFFF0ull / per_sample64;
+        if (batch > fit) batch = fit ? fit : 1;
+        if (batch > fit32) batch = fit32;
     }
 
     // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row
@@ -661,7 +696,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     // ---- scratch: one RGB per ray of a sample batch, the running per-pixel sum, the SoA ray state
     if (spp > 0) {
-        if (int32_t rc = grow((void **)&h->samples, &h->samples_bytes, (size_t)(batch * npix * 3 * sizeof(double)))) return rc;
+        if (int32_t rc = grow((void **)&h->samples, &h->samples_bytes, (size_t)(batch * per_sample64 * 4 * sizeof(double)))) return rc;
     }
     if (batch < spp) {
         if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
@@ -690,18 +725,15 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     if (spp == 0) {
         // avg() of an empty iterator: 0/0 = NaN per component (scene.rs:253-259)
-        RTX_HIP_CHECK(launch_resolve(nullptr, nullptr, d_out_rgb, npix, 0, 0, true, true, stream));
+        rv.n_samples = 0; rv.n_rays = 0; rv.tiles_x = 0;
+        RTX_HIP_CHECK(launch_resolve(nullptr, nullptr, d_out_rgb, rv, npix, 0, true, true, stream));
     }
     for (uint64_t s0 = 0; s0 < spp; s0 += batch) {
         const uint64_t ns = (spp - s0 < batch) ? spp - s0 : batch;
         rv.sample_begin = (uint32_t)s0;
         rv.n_samples = (uint32_t)ns;
-        rv.n_rays = (uint64_t)npix * ns;
-        rv.tiles_x = 0;
-        if ((kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) && !std::getenv("RTX_HIP_NO_TILES")) {
-            rv.tiles_x = (width + 7u) / 8u;
-            rv.n_rays = (uint64_t)rv.tiles_x * ((n_rows + 7u) / 8u) * 64u * ns;        // the padded tile grid
-        }
+        rv.n_rays = per_sample64 * ns;                      // (the padded tile grid when tiled)
+        rv.tiles_x = tiles_x;
         {
             const uint64_t per_wave = rv.n_rays / ((uint64_t)h->n_cus * 16u * 8u);       // 16 resident waves per CU
             rv.grab = (uint32_t)(per_wave >= 512 ? 512 : (per_wave <= 64 ? 64 : (per_wave & ~(uint64_t)63)));
@@ -725,7 +757,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         }
         ++launches;
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[1], stream));
-        RTX_HIP_CHECK(launch_resolve(h->samples, h->acc, d_out_rgb, npix, (uint32_t)ns, spp, s0 == 0, s0 + ns == spp, stream));
+        RTX_HIP_CHECK(launch_resolve(h->samples, h->acc, d_out_rgb, rv, per_sample, spp, s0 == 0, s0 + ns == spp, stream));
         if (stats) {
             RTX_HIP_CHECK(hipEventRecord(h->ev[2], stream));
             RTX_HIP_CHECK(hipEventSynchronize(h->ev[2]));
@@ -960,18 +992,23 @@ int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
             const uint32_t n = count & 0xFFFFu;
             stats[10] = std::max<uint64_t>(stats[10], n);
             if (count & kBvhTriLeaf) {
-                if (!flat && !(std::isinf(b.lo[2]) && std::isinf(b.hi[2]))) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle leaf with a bounded z slab");
                 for (uint32_t k = 0; k < n; ++k) {
                     const uint32_t rec = link + k;
                     if (rec >= p.sv.n_tri_tree) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle record out of range");
                     if (tri_seen[rec]++) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle in two leaves");
-                    const RtxObject &o = scene->objects[p.tris[p.tri_fidx[rec]].id];
+                    const TriX &tx = p.tris[p.tri_fidx[rec]];
+                    const RtxObject &o = scene->objects[tx.id];
+                    const int free_axis = p.tri_rec_free_axis[rec];
+                    if (free_axis != 3 - (int)tx.i - (int)tx.j) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: footprint plane differs from the elimination's rows");
+                    if (flat && free_axis != 2) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: a flat node holds a triangle that is not solved in (x, y)");
+                    if (!(std::isinf(b.lo[free_axis]) && std::isinf(b.hi[free_axis]))) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: triangle leaf bounded along the axis its test does not read");
                     BvhBox fp;
-                    if (!triangle_footprint(o.geom, fp)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: non-finite triangle in the tree");
-                    for (int a = 0; a < 2; ++a)
-                        if (!((double)b.lo[a] <= fp.lo[a] && (double)b.hi[a] >= fp.hi[a]))
+                    if (!triangle_footprint(o.geom, fp, free_axis)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: non-finite triangle in the tree");
+                    for (int a = 0; a < 3; ++a)
+                        if (a != free_axis && !((double)b.lo[a] <= fp.lo[a] && (double)b.hi[a] >= fp.hi[a]))
                             return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: footprint outside its leaf");
                     stats[9] += 1;
+                    stats[13 + (free_axis == 2 ? 0 : 1)] += 1;          // 13: (x, y) footprints, 14: (x, z) and (y, z)
                 }
             } else {
                 for (uint32_t k = 0; k < n; ++k) {

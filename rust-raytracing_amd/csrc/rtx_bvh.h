@@ -61,6 +61,7 @@ struct BvhBuild {
     std::vector<BvhNode> nodes;
     std::vector<uint32_t> prims;          // local sphere indices, leaf-contiguous
     std::vector<uint32_t> tri_order;      // triangle (footprint) indices, leaf-contiguous
+    std::vector<uint8_t> flat;            // per node: 1 = a node of the (x, y) footprint sub-tree (gets the flat 2-D layout)
     bool has_spheres = false, has_tris = false;
     // The traversal's slab test runs in f32: t = fl(b * inv + noi), inv = fl(1/d), noi = fl(-o * inv) (rtx_traverse.h).
     // Rounding noi shifts both faces of an axis by at most 2^-24 |o|, the other roundings are a relative error
@@ -99,10 +100,13 @@ inline bool sphere_box(const double s[4], BvhBox &b)
     return true;
 }
 
-// triangle.rs:190-194 restricted to (x, y): min/max of the vertices, same inflation; z unbounded (see the top).
-inline bool triangle_footprint(const double v[9], BvhBox &b)
+// triangle.rs:190-194 restricted to the coordinate plane Triangle::contains solves in -- `free_axis` is the axis the
+// elimination does not read (2: the usual (x, y) rows; 1 / 0: the (x, z) / (y, z) rows a zero pivot swaps in,
+// triangle.rs:60-71,81-87): min/max of the vertices in the plane, same inflation; unbounded along free_axis.
+inline bool triangle_footprint(const double v[9], BvhBox &b, int free_axis = 2)
 {
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < 3; ++a) {
+        if (a == free_axis) { b.lo[a] = -INFINITY; b.hi[a] = INFINITY; continue; }
         const double x0 = v[a], x1 = v[3 + a], x2 = v[6 + a];
         if (!std::isfinite(x0) || !std::isfinite(x1) || !std::isfinite(x2)) return false;
         const double lo = std::fmin(x0, std::fmin(x1, x2)), hi = std::fmax(x0, std::fmax(x1, x2));
@@ -110,8 +114,6 @@ inline bool triangle_footprint(const double v[9], BvhBox &b)
         b.lo[a] = lo - pad;
         b.hi[a] = hi + pad;
     }
-    b.lo[2] = -INFINITY;
-    b.hi[2] = INFINITY;
     return true;
 }
 
@@ -127,20 +129,23 @@ inline bool triangle_footprint(const double v[9], BvhBox &b)
 constexpr int kBvhSahBins = RTX_BVH_SAH_BINS;
 constexpr int kBvhSahExtraDepth = 6;
 
+// `free_axis` (dims == 2 only): the axis the boxes are unbounded along; the splits use the other two.
 inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t leaf_size, uint32_t leaf_flag,
-                            BvhBuild &out, std::vector<uint32_t> &order_out, bool use_sah = true)
+                            BvhBuild &out, std::vector<uint32_t> &order_out, bool use_sah = true, int free_axis = 2,
+                            uint32_t order_base = 0)
 {
     const uint32_t n = (uint32_t)box.size();
+    const int ax[3] = { dims == 2 && free_axis == 0 ? 1 : 0, dims == 2 && free_axis != 2 ? 2 : 1, 2 };   // split axes
     std::vector<double> cen((size_t)dims * n);
     for (uint32_t i = 0; i < n; ++i)
-        for (int a = 0; a < dims; ++a) cen[(size_t)dims * i + a] = 0.5 * (box[i].lo[a] + box[i].hi[a]);
+        for (int a = 0; a < dims; ++a) cen[(size_t)dims * i + a] = 0.5 * (box[i].lo[ax[a]] + box[i].hi[ax[a]]);
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     int balanced_depth = 1;
     for (uint64_t c = leaf_size; c < n; c *= 2) ++balanced_depth;
     const int max_depth = balanced_depth + kBvhSahExtraDepth;
-    auto measure = [dims](const BvhBox &b) {
-        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1];
+    auto measure = [dims, &ax](const BvhBox &b) {
+        const double dx = b.hi[ax[0]] - b.lo[ax[0]], dy = b.hi[ax[1]] - b.lo[ax[1]];
         if (dims == 2) return dx + dy;
         const double dz = b.hi[2] - b.lo[2];
         return dx * dy + dy * dz + dz * dx;
@@ -180,7 +185,7 @@ inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t l
         if (cnt <= leaf_size) {
             node.link = (uint32_t)order_out.size();
             node.count = cnt | leaf_flag;
-            for (uint32_t k = t.begin; k < t.end; ++k) order_out.push_back(order[k]);
+            for (uint32_t k = t.begin; k < t.end; ++k) order_out.push_back(order_base + order[k]);
             out.nodes.push_back(node);
             continue;
         }
@@ -261,17 +266,19 @@ inline void bvh_append_tree(const std::vector<BvhBox> &box, int dims, uint32_t l
     }
 }
 
-// One tree over the sphere boxes (3-D) and the triangle footprints (x, y; z unbounded).  When both kinds are
-// present the root is an interior node whose children are the two sub-trees, so one traversal orders and prunes
-// across both.  Either vector may be empty; a kind with fewer than 5 members gets no sub-tree (has_* = false, the
-// kernel tests those shapes for every segment).  Returns an empty build when the coordinates are too large for
-// the f32 slab test.
-inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::vector<BvhBox> &tri_boxes, uint32_t tri_leaf_size,
+// One tree over the sphere boxes (3-D) and the triangle footprints.  tri_boxes[f] holds the footprints of the triangles
+// whose elimination does not read axis f (f = 2: the (x, y) plane, the usual case; 1: (x, z); 0: (y, z)), unbounded along f.
+// Every non-empty set gets its own sub-tree (a 2-D build in its plane); the sub-trees hang off a chain of joint nodes at
+// the front, so one traversal orders and prunes across all of them.  The caller passes only sets it wants in the tree
+// (more than 4 members).  tri_order indexes the concatenation [tri_boxes[2]] [tri_boxes[1]] [tri_boxes[0]].  Returns an
+// empty build when the coordinates are too large for the f32 slab test.
+inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::vector<BvhBox> (&tri_boxes)[3], uint32_t tri_leaf_size,
                           bool use_sah = true)
 {
     BvhBuild out;
-    const bool want_s = sphere_boxes.size() > 4, want_t = tri_boxes.size() > 4;
-    if (!want_s && !want_t) return out;
+    const bool want_s = !sphere_boxes.empty();
+    const size_t n_tri = tri_boxes[0].size() + tri_boxes[1].size() + tri_boxes[2].size();
+    if (!want_s && n_tri == 0) return out;
     double scale = 0.0;
     auto grow_scale = [&](const std::vector<BvhBox> &v) {
         for (const BvhBox &b : v)
@@ -280,28 +287,48 @@ inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::ve
                 if (std::isfinite(b.hi[a])) scale = std::max(scale, std::fabs(b.hi[a]));
             }
     };
-    if (want_s) grow_scale(sphere_boxes);
-    if (want_t) grow_scale(tri_boxes);
+    grow_scale(sphere_boxes);
+    for (const auto &v : tri_boxes) grow_scale(v);
     out.origin_limit = 4.0 * scale + 1.0;
     out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
     if (!(out.origin_limit < 1.0e28)) return BvhBuild();
-    if (sphere_boxes.size() + tri_boxes.size() >= 0x20000000ull) return BvhBuild();          // node indices must stay below kBvhFlatNode
+    if (sphere_boxes.size() + n_tri >= 0x20000000ull) return BvhBuild();          // node indices must stay below kBvhFlatNode
     if (tri_leaf_size < 1) tri_leaf_size = 1;
     if (tri_leaf_size > (uint32_t)kBvhTriLeafMax) tri_leaf_size = (uint32_t)kBvhTriLeafMax;
-    out.nodes.reserve(2 * (sphere_boxes.size() + tri_boxes.size()) + 4);
-    if (want_s && want_t) out.nodes.emplace_back();                 // joint root, filled in below
-    if (want_s) { bvh_append_tree(sphere_boxes, 3, (uint32_t)kBvhLeafSize, 0u, out, out.prims, use_sah); out.has_spheres = true; }
-    const uint32_t tri_root = (uint32_t)out.nodes.size();
-    if (want_t) { bvh_append_tree(tri_boxes, 2, tri_leaf_size, kBvhTriLeaf, out, out.tri_order, use_sah); out.has_tris = true; }
-    if (want_s && want_t) {
-        BvhNode root;
-        for (int a = 0; a < 3; ++a) {
-            root.lo[a] = std::min(out.nodes[1].lo[a], out.nodes[tri_root].lo[a]);
-            root.hi[a] = std::max(out.nodes[1].hi[a], out.nodes[tri_root].hi[a]);
+    out.nodes.reserve(2 * (sphere_boxes.size() + n_tri) + 8);
+    struct Sub { const std::vector<BvhBox> *boxes; int free_axis; uint32_t base; };      // free_axis < 0: the spheres
+    std::vector<Sub> subs;
+    if (want_s) subs.push_back({&sphere_boxes, -1, 0u});
+    uint32_t base = 0;
+    for (int f = 2; f >= 0; --f) {
+        if (!tri_boxes[f].empty()) subs.push_back({&tri_boxes[f], f, base});
+        base += (uint32_t)tri_boxes[f].size();
+    }
+    std::vector<uint32_t> joints;
+    for (size_t k = 0; k < subs.size(); ++k) {
+        if (k + 1 < subs.size()) {                                  // a joint: left child = this sub-tree, right child = the rest
+            joints.push_back((uint32_t)out.nodes.size());
+            out.nodes.emplace_back();
+        } else if (!joints.empty()) {
+            out.nodes[joints.back()].link = (uint32_t)out.nodes.size();        // the last sub-tree is the last joint's right child
         }
-        root.link = tri_root;
-        root.count = 0;
-        out.nodes[0] = root;
+        if (k > 0 && k + 1 < subs.size()) out.nodes[joints[k - 1]].link = joints[k];
+        const size_t first = out.nodes.size();
+        if (subs[k].free_axis < 0) {
+            bvh_append_tree(*subs[k].boxes, 3, (uint32_t)kBvhLeafSize, 0u, out, out.prims, use_sah);
+            out.has_spheres = true;
+        } else {
+            bvh_append_tree(*subs[k].boxes, 2, tri_leaf_size, kBvhTriLeaf, out, out.tri_order, use_sah, subs[k].free_axis, subs[k].base);
+            out.has_tris = true;
+        }
+        out.flat.resize(out.nodes.size(), 0);
+        if (subs[k].free_axis == 2) std::fill(out.flat.begin() + (ptrdiff_t)first, out.flat.end(), (uint8_t)1);
+    }
+    for (size_t k = joints.size(); k-- > 0;) {                     // joint boxes, innermost first
+        BvhNode &j = out.nodes[joints[k]];
+        const BvhNode &l = out.nodes[joints[k] + 1], &r = out.nodes[j.link];
+        for (int a = 0; a < 3; ++a) { j.lo[a] = std::min(l.lo[a], r.lo[a]); j.hi[a] = std::max(l.hi[a], r.hi[a]); }
+        j.count = 0;
     }
     return out;
 }
@@ -343,17 +370,16 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
 {
     Bvh4Build out;
     if (b2.nodes.empty()) return out;
-    auto area = [&](uint32_t i) {
-        const BvhNode &n = b2.nodes[i];
-        const double dx = (double)n.hi[0] - n.lo[0], dy = (double)n.hi[1] - n.lo[1], dz = (double)n.hi[2] - n.lo[2];
-        if (!std::isfinite(dz)) return dx + dy;                  // footprint node: what a 2-D ray can hit is its perimeter
-        return dx * dy + dy * dz + dz * dx;
+    auto area = [&](uint32_t i) {                                  // what a ray can hit: the area, or -- for a footprint node,
+        const BvhNode &n = b2.nodes[i];                            // unbounded along one axis -- the perimeter in its plane
+        double e[3], fin[3];
+        int nf = 0;
+        for (int a = 0; a < 3; ++a) { e[a] = (double)n.hi[a] - n.lo[a]; if (std::isfinite(e[a])) fin[nf++] = e[a]; }
+        if (nf == 3) return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+        if (nf == 2) return fin[0] + fin[1];
+        return (double)INFINITY;                                   // a joint over several planes: open it first
     };
-    const bool joint = b2.has_spheres && b2.has_tris;              // binary node 0 then joins the two sub-trees
-    auto flat = [&](uint32_t bin) {                                // a node of the triangle sub-tree
-        const BvhNode &n = b2.nodes[bin];
-        return std::isinf(n.lo[2]) && std::isinf(n.hi[2]) && !(joint && bin == 0u);
-    };
+    auto flat = [&](uint32_t bin) { return bin < b2.flat.size() && b2.flat[bin] != 0; };     // a node of the (x, y) sub-tree
     struct Task { uint32_t bin; uint32_t wide; int depth; };
     std::vector<Task> todo;
     out.nodes.emplace_back();

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
     bool queue_empty = false;
     bool alive = false;
     RayState r;
-    uint32_t pl = 0, smp = 0;
+    uint32_t ridx = 0;                       // the ray's index in the launch's queue = where its sample goes
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
     unsigned long long wave_steps = 0;      // (-DRTX_BVH_STATS: traversal-loop iterations of the wave, reported via exact_tests)
 #ifdef RTX_BVH_STATS
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
             if (!alive && wave_next < wave_end) {
                 const unsigned long long my = wave_next + bvh_mbcnt(idle_mask);
                 bool valid = my < wave_end;
+                uint32_t pl = 0, smp = 0;
                 if (valid) {
                     if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
                     else ray_index_to_pixel(rv, my, pl, smp);
@@ -83,9 +84,9 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                 if (valid) {
                     gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
                     alive = true;
+                    ridx = (uint32_t)my;                                          // (the host keeps rv.n_rays below 2^32)
                     if (sv.n_objects == 0) {                                      // scene.rs:224-226
-                        double *o = samples + ((uint64_t)smp * rv.npix + pl) * 3;
-                        o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
+                        store_sample(samples, rv, ridx, mk(0.0, 0.0, 0.0));
                         alive = false;
                     }
                 }
@@ -160,8 +161,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_kerne
                 done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
             }
             if (done) {
-                double *o = samples + ((uint64_t)smp * rv.npix + pl) * 3;
-                o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+                store_sample(samples, rv, ridx, r.result);
                 alive = false;
             }
         }

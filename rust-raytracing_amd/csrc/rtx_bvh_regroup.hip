@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
     float best_up = 0.f;
     uint32_t node = kNone, sp = 0, qcnt = 0, nbox = 0, nleaf = 0;
     bool overflow = false, tree_used = false;
-    uint32_t pl = 0, smp = 0, wave_step = 0;
+    uint32_t ridx = 0, wave_step = 0;        // ridx: the ray's index in the launch's queue = where its sample goes
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
     hit_init(h);
     filter_idle(fpar);
@@ -102,8 +102,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
                 done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
             }
             if (done) {
-                double *o = samples + ((uint64_t)smp * rv.npix + pl) * 3;
-                o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+                store_sample(samples, rv, ridx, r.result);
                 state = S_IDLE;
             } else {
                 state = S_SETUP;
@@ -125,6 +124,7 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
             if (state == S_IDLE) {
                 const unsigned long long my = wave_next + bvh_mbcnt(idle_mask);
                 bool valid = my < wave_end;
+                uint32_t pl = 0, smp = 0;
                 if (valid) {
                     if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
                     else ray_index_to_pixel(rv, my, pl, smp);
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(kBvhThreads, kBvhWavesPerSimd) void trace_bvh_regro
                 if (valid) {
                     gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
                     state = S_SETUP;
+                    ridx = (uint32_t)my;                                          // (the host keeps rv.n_rays below 2^32)
                     if (sv.n_objects == 0) {                                      // scene.rs:224-226
-                        double *o = samples + ((uint64_t)smp * rv.npix + pl) * 3;
-                        o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
+                        store_sample(samples, rv, ridx, mk(0.0, 0.0, 0.0));
                         state = S_IDLE;
                     }
                 }

@@ -124,6 +124,18 @@ __device__ __forceinline__ bool ray_index_to_pixel_tiled(const RowsView &rv, uin
     return x < rv.width && k < rv.n_rows;
 }
 
+// Samples: one 32-byte record {r, g, b, 0} per ray, in RAY-QUEUE order (rv.n_rays of them, the padding of partial
+// tiles included).  A ray finishes on its own lane at its own time, so its store is a lone lane's: the record is one
+// whole 32-byte sector, which is what the memory side writes anyway.  Measured on C2 at 64 spp (WRITE_SIZE per launch
+// for 3.19 GB of samples): [pixel][3] doubles, 24 B across two sectors: 9.4 GB; three 8-byte planes: 13.6 GB (one
+// sector per 8-byte store -- L2 does not merge them before they leave); this layout: see profiles/.
+__device__ __forceinline__ void store_sample(double *__restrict__ samples, const RowsView &rv, uint64_t ridx, V3 c)
+{
+    (void)rv;
+    double4 *rec = reinterpret_cast<double4 *>(samples) + ridx;
+    *rec = make_double4(c.x, c.y, c.z, 0.0);
+}
+
 // render_pixel's per-sample prologue (scene.rs:196-207) + get_ray_dir (scene.rs:213-222).
 __device__ __forceinline__ void gen_primary(const SceneView &sv, const RowsView &rv, uint32_t pl, uint32_t sample,
                                             RayState &r)

@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256) void trace_exact_kernel(const SceneView *__res
                 advance_and_shade(sv, h, r);
             }
         }
-        double *o = samples + ((uint64_t)s_local * rv.npix + pl) * 3;
-        o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+        store_sample(samples, rv, i, r.result);
     }
     flush_counters(ctr, segs, segs * sv.n_objects, 0);
 }
@@ -226,8 +225,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                         RayState r;
                         gen_primary(sv, rv, p, rv.sample_begin + sl, r);
                         if (sv.n_objects == 0) {                                  // scene.rs:224-226
-                            double *o = samples + ((uint64_t)sl * rv.npix + p) * 3;
-                            o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
+                            store_sample(samples, rv, my, mk(0.0, 0.0, 0.0));
                         } else {
                             const uint64_t slot = lane_gid + (uint64_t)s * n_lanes;
                             double *st = state + slot;
@@ -448,8 +446,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                 }
             }
             if (done) {
-                double *o = samples + ((uint64_t)smp * rv.npix + pl) * 3;
-                o[0] = r.result.x; o[1] = r.result.y; o[2] = r.result.z;
+                store_sample(samples, rv, (uint64_t)smp * rv.npix + pl, r.result);      // = the ray's queue index (ray_index_to_pixel)
                 live &= ~(1u << s);
             }
         }
@@ -463,18 +460,29 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
 
 // ------------------------------------------------------------------------------------------
 // resolve: avg() (scene.rs:253-259) = left fold from zeros (iter_ops.rs:4-8), then / len
+// One thread per slot of a sample's queue order (tiles_x != 0: 8x8 pixel tiles, padding slots skipped); consecutive
+// threads read consecutive 32-byte records {r, g, b, 0}, sample after sample.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resolve_kernel(const double *__restrict__ samples, double *__restrict__ acc,
-                                                      double *__restrict__ out, uint32_t npix, uint32_t n_samples,
+                                                      double *__restrict__ out, uint32_t width, uint32_t n_rows, uint32_t tiles_x,
+                                                      uint32_t per_sample, uint32_t n_samples,
                                                       double divisor, int first, int last)
 {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_sample) return;
+    uint32_t p = t;                                   // local pixel k * width + x
+    if (tiles_x != 0u) {
+        const uint32_t tile = t >> 6, j = t & 63u;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const uint32_t x = tx * 8u + (j & 7u), k = ty * 8u + (j >> 3);
+        if (x >= width || k >= n_rows) return;
+        p = k * width + x;
+    }
     double sx = 0.0, sy = 0.0, sz = 0.0;
     if (!first) { sx = acc[3 * (uint64_t)p]; sy = acc[3 * (uint64_t)p + 1]; sz = acc[3 * (uint64_t)p + 2]; }
     for (uint32_t s = 0; s < n_samples; ++s) {
-        const double *c = samples + ((uint64_t)s * npix + p) * 3;
-        sx = sx + c[0]; sy = sy + c[1]; sz = sz + c[2];
+        const double4 c = reinterpret_cast<const double4 *>(samples)[(uint64_t)s * per_sample + t];
+        sx = sx + c.x; sy = sy + c.y; sz = sz + c.z;
     }
     if (last) {
         double *o = out + 3 * (uint64_t)p;
@@ -632,12 +640,12 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
     return hipLaunchKernel(v.fn, dim3(blocks), dim3(v.threads), args, v.lds, stream);
 }
 
-hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,
+hipError_t launch_resolve(const double *samples, double *acc, double *out, const RowsView &rv, uint32_t per_sample,
                           uint64_t rays_per_pixel, bool first, bool last, hipStream_t stream)
 {
-    if (npix == 0) return hipSuccess;
-    hipLaunchKernelGGL(resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, samples, acc, out, npix,
-                       n_samples, (double)rays_per_pixel, first ? 1 : 0, last ? 1 : 0);
+    if (per_sample == 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((per_sample + 255) / 256), dim3(256), 0, stream, samples, acc, out, rv.width, rv.n_rows,
+                       rv.tiles_x, per_sample, rv.n_samples, (double)rays_per_pixel, first ? 1 : 0, last ? 1 : 0);
     return hipGetLastError();
 }
 

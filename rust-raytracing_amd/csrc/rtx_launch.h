@@ -5,7 +5,7 @@
 
 namespace rtx {
 
-// samples: [n_samples][npix][3] doubles (one RGB per ray), written by the trace kernels.
+// samples: rv.n_rays records {r, g, b, 0} (32 B) in ray-queue order (store_sample, rtx_device.h), written by the trace kernels.
 // d_sv / d_rv: device copies of the scene and launch descriptors (sv / rv are the host originals).
 hipError_t launch_trace_exact(const SceneView *d_sv, const RowsView *d_rv, const RowsView &rv, double *samples,
                               Counters *counters, hipStream_t stream);
@@ -34,9 +34,11 @@ hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, 
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill,
                                     int n_cus, hipStream_t stream);
 
-// Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in
-// sample order).  first: acc starts from zero.  last: out[p] = acc / rays_per_pixel.
-hipError_t launch_resolve(const double *samples, double *acc, double *out, uint32_t npix, uint32_t n_samples,
+// Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in sample order).
+// samples: rv.n_rays 32-byte records in ray-queue order (store_sample, rtx_device.h); per_sample = queue slots
+// of one sample (npix, or the padded 8x8-tile grid when rv.tiles_x != 0).  first: acc starts from zero.
+// last: out[p] = acc / rays_per_pixel (rays_per_pixel == 0 with rv.n_samples == 0: 0/0 = NaN, as avg() of nothing).
+hipError_t launch_resolve(const double *samples, double *acc, double *out, const RowsView &rv, uint32_t per_sample,
                           uint64_t rays_per_pixel, bool first, bool last, hipStream_t stream);
 
 // render_to_image epilogue (scene.rs:175-178)

@@ -78,6 +78,26 @@ def random_triangles(n=100000, seed=2, box=1.0):
     return o
 
 
+def axis_aligned_mesh(n_cubes=800, seed=5, span=6.0, x0=8.0):
+    """Cubes of random size made of 12 triangles each: every face lies in a plane x, y or z = const, so Triangle::contains
+    meets zero pivots and solves most faces in the (y, z) or (x, z) rows (triangle.rs:60-71,81-87) -- the mesh shape real
+    models have and the random BASELINE meshes do not."""
+    u = splitmix_u01(seed, 8 * n_cubes).reshape(n_cubes, 8)
+    c = np.stack([x0 + span * u[:, 0], span * (u[:, 1] - 0.5), span * (u[:, 2] - 0.5)], axis=1)
+    hs = 0.05 + 0.25 * u[:, 3]
+    corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    # two triangles per face, as corner indices (bit 2 = x, bit 1 = y, bit 0 = z)
+    faces = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+    o = np.zeros(12 * n_cubes, dtype=OBJECT_DTYPE)
+    o["kind"] = RTX_TRIANGLE
+    vtx = c[:, None, :] + hs[:, None, None] * corners[None, :, :]                # (n, 8, 3)
+    geom = np.stack([vtx[:, list(f), :].reshape(n_cubes, 9) for f in faces], axis=1)   # (n, 12, 9)
+    o["geom"] = geom.reshape(-1, 9)
+    uk = np.repeat(u[:, 4], 12); uc = np.repeat(u[:, 5:8], 12, axis=0)
+    _materials(o, np.where(uk < 0.3, 0.0, 1.0), uc, np.repeat(u[:, 3], 12))      # 30 % of the cubes are lights
+    return o
+
+
 def compact(objs, k=0.08, x0=4.0):
     """Moves spheres/triangles of the C2/C3 recipes close to the camera (centres x -> x0 + (x-10)*k, y,z -> *k;
     sphere radii * 0.6, triangle shapes kept) so that small test scenes have most rays hitting something."""

@@ -280,6 +280,15 @@ def test_bvh_invariants_on_the_benchmark_scenes(rtx):
     assert st["flags"] == 3 and st["sphere_leaf_entries"] == 60 and 0 < st["flat_nodes"] < st["wide_nodes"]
     st = _host_scene(rtx, scenes.three_spheres())                                # C1: too small for a tree
     assert st["wide_nodes"] == 0 and st["flags"] == 0
+    # faces in planes x / y / z = const: Triangle::contains swaps pivot rows (triangle.rs:60-71,81-87) and solves them in
+    # (y, z) / (x, z); they enter the tree with the footprint in THAT plane instead of being tested for every segment
+    st = _host_scene(rtx, scenes.axis_aligned_mesh())
+    assert st["tri_in_tree"] == st["tri_filter_records"] == st["tri_leaf_entries"] > 5000
+    assert st["tri_xy_footprints"] > 1500 and st["tri_other_footprints"] > 3000
+    assert st["tri_xy_footprints"] + st["tri_other_footprints"] == st["tri_in_tree"] and 0 < st["flat_nodes"] < st["wide_nodes"]
+    st = _host_scene(rtx, np.concatenate([scenes.random_spheres(3000, 1), scenes.axis_aligned_mesh(), scenes.random_triangles(5000, 2)]))
+    assert st["flags"] == 3 and st["sphere_leaf_entries"] == 3000 and st["tri_in_tree"] == st["tri_filter_records"]
+    assert st["tri_other_footprints"] > 3000
 
 
 def test_bvh_invariants_on_awkward_and_random_scenes(rtx):

@@ -200,6 +200,68 @@ def test_bvh_triangle_footprint_tree_is_bit_identical_to_exact_kernel(gpu, n_tri
     assert c[3] in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP) and np.array_equal(a[0], c[0])       # AUTO picks the tree for triangle meshes
 
 
+def test_axis_aligned_mesh_stays_inside_the_tree(gpu, oracle):
+    """A mesh of axis-aligned cubes: most faces are solved by Triangle::contains in the (y, z) or (x, z) rows
+    (zero-pivot swaps, triangle.rs:60-71,81-87).  They sit in the tree with footprints in those planes (none is left to
+    the per-segment sweep, so AUTO keeps the tree kernels).  Checks, from the benchmark camera, from inside the mesh and
+    looking straight along each axis:
+      * every kernel's frame and segment count equal the exhaustive f64 kernel's bit for bit;
+      * with every face a light (paths end at the first hit: no bounce, no sin/cos) every pixel equals the oracle's;
+      * with bouncing materials all but a handful of pixels equal the oracle's.  The handful is the stated sin/cos
+        divergence meeting this geometry: a hit point on a face x = const is p.x = o.x + d.x * ((v0.x - o.x) / d.x),
+        which lands on v0.x exactly or one ulp off; the bounced ray's self-test then returns distance 0 (filtered by
+        is_normal, scene.rs:249: the ray leaves) or 1e-16 (a self-hit: it bounces again).  A 1-ulp difference in a bounce
+        direction (device sincos vs glibc, <= 1 ulp on ~3 % of arguments) flips that coin for a later hit, and the path
+        changes -- between two libm versions of the reference itself just as well."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.axis_aligned_mesh()
+    st = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), objs))
+    assert st["tri_in_tree"] == st["tri_filter_records"] and st["tri_other_footprints"] > 3000
+    lights = objs.copy()
+    lights["emission_color"] = 0.25 + 0.75 * np.abs(np.sin(np.arange(len(objs))[:, None] * np.array([0.37, 0.61, 0.83])))
+    lights["base_color"] = 0.0
+    cams = [scenes.CAMERA, ((11.0, 0.2, 0.1), (0.3, 1.0, 0.2), 1.4), ((11.0, 0.0, 6.0), (0.0, 0.0, -1.0), 1.2),
+            ((11.0, -6.0, 0.0), (0.0, 1.0, 0.0), 1.2), ((2.0, 0.0, 0.0), (1.0, 0.0, 0.0), 0.8)]
+    w, h, spp = 96, 54, 2
+
+    def run(ob, cam, kern):
+        hnd = hip_scene(gpu, ob, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42).upload(0)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        stt = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        hnd.close()
+        return buf.cpu().numpy(), stt.segments, stt.kernel
+
+    lit = flipped = 0
+    for cam in cams:
+        ref_l = oracle_render(oracle, lights, w, h, cam=cam, rays_per_pixel=spp, seed=42)
+        ref_b = oracle_render(oracle, objs, w, h, cam=cam, rays_per_pixel=spp, seed=42)
+        lit += ref_l.mean() > 0.01
+        for ob, ref, exact_everywhere in ((lights, ref_l, True), (objs, ref_b, False)):
+            imgs = {kern: run(ob, cam, kern) for kern in [gpu.RTX_KERNEL_AUTO] + _kernels(gpu)}
+            assert imgs[gpu.RTX_KERNEL_AUTO][2] == gpu.RTX_KERNEL_BVH_REGROUP   # the tree holds the mesh: no fallback to the sweep
+            ex = imgs[gpu.RTX_KERNEL_EXACT]
+            for kern in imgs:
+                assert np.array_equal(imgs[kern][0], ex[0]) and imgs[kern][1] == ex[1], (cam, kern)
+            bad = int((np.abs(ex[0] - ref).max(axis=2) > ATOL).sum())
+            if exact_everywhere:
+                assert bad == 0, cam
+            else:
+                assert bad <= 0.004 * w * h, (cam, bad)
+                flipped += bad
+    assert lit >= 3
+    # the same mesh next to spheres and a random mesh: four sub-trees under the joint nodes
+    mix = np.concatenate([scenes.compact(scenes.random_spheres(400, 3), k=0.06, x0=9.0), lights[::3],
+                          scenes.light_every(scenes.compact(scenes.random_triangles(900, 4), k=0.06, x0=9.0))])
+    stm = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), mix))
+    assert stm["flags"] == 3 and stm["tri_other_footprints"] > 900 and stm["tri_xy_footprints"] > 300
+    ex = hip_render(gpu, mix, w, h, kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=spp, seed=7)
+    for kern in _kernels(gpu):
+        assert np.array_equal(hip_render(gpu, mix, w, h, kernel=kern, rays_per_pixel=spp, seed=7), ex), kern
+    ref = oracle_render(oracle, mix, w, h, rays_per_pixel=spp, seed=7)
+    assert int((np.abs(ex - ref).max(axis=2) > ATOL).sum()) <= 0.004 * w * h and ref.mean() > 0.01
+
+
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
     """Spheres + triangles + a plane under one root; camera variants: inside the cloud looking along -z (rays nearly
     parallel to the footprints' unbounded axis), exactly axis-parallel directions (0 * inf in the slab test), and far
