@@ -62,10 +62,13 @@ CONFIGS = {
                name="1M random triangles (scene seed 3, box x2), 3840x2160, flat BVH"),
 }
 KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 filter sweep + exact f64 (trace_mixed_kernel)",
-                3: "trace_mixed_kernel + verify", 4: "flat 4-wide BVH, lock-step waves (trace_bvh_kernel)",
+                3: "trace_mixed_kernel + verify",
+                4: "flat 4-wide BVH, lock-step waves (trace_bvh_spheres_kernel: f32-only traversal loop, exact f64 tests after the "
+                   "walk; trace_bvh_kernel when the tree holds triangles)",
                 5: "flat 4-wide BVH, regrouping schedule (trace_bvh_regroup_kernel)"}
-KERNEL_SYMBOL = {1: "trace_exact_kernel", 2: "trace_mixed_kernel", 3: "trace_mixed_kernel", 4: "trace_bvh_kernel",
-                 5: "trace_bvh_regroup_kernel"}
+# substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
+KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
+                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel",)}
 # lane-op prices of the algorithmic counts (what the chosen algorithm needs at least; f64 instructions issue at half rate
 # and count double).  box test: 6 fma + 9 min/max + 2 mul + 2 cmp; sphere filter: 7 fma + 1 sub; triangle filter: 16;
 # exact sphere test (sphere.rs:19-30): 17 f64 add/mul + sqrt + div (~14 f64 instructions each) = 45 f64 -> 90; exact
@@ -237,7 +240,7 @@ def pmc_collect(leg, kernel_symbol, log):
             acc, cnt, dur = {}, {}, []
             for f in files:
                 for r in csv.DictReader(open(f)):
-                    if kernel_symbol not in r.get("Kernel_Name", ""):
+                    if not any(sym in r.get("Kernel_Name", "") for sym in kernel_symbol):
                         continue
                     k = r["Counter_Name"]
                     acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
@@ -250,7 +253,7 @@ def pmc_collect(leg, kernel_symbol, log):
             if name == "fetch" and dur:
                 got["_pmc_launch_s"] = sum(dur) / len(dur)
             if not any(k in acc for k in counters):
-                return None, "no rows of %s in pass '%s'" % (kernel_symbol, name)
+                return None, "no rows of %s in pass '%s'" % ("/".join(kernel_symbol), name)
     except Exception as e:                                     # noqa: BLE001 -- a profiler problem must not fail the bench
         return None, "rocprofv3: %r" % (e,)
     finally:
@@ -470,7 +473,7 @@ def main():
             hnd.close()
             rays = n_rows * oc["w"] * s * 2
             leg = "%s:%d:%s:0" % (name, s, "band" if band else "full")
-            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, "trace_"), live_pmc and name in ("C3", "C5"), log)
+            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, ("trace_",)), live_pmc and name in ("C3", "C5"), log)
             others.append({
                 "config": name, "workload": "%s, %s at %d spp (the config names %d spp; Mrays/s is a rate)" % (
                     oc["name"], "the interleaved row band rank 0 of 8 owns (%d rows)" % n_rows if band else "full frame", s, oc["spp"]),
@@ -483,7 +486,7 @@ def main():
         steps = max(args.steps, 1)
         rays_per_step = W * H * spp
         value = rays_per_step * args.steps / elapsed / 1e6 if args.steps else 0.0
-        cnt, src = (counters_for("%s:%d:full:%d" % (args.config, spp, args.kernel), KERNEL_SYMBOL.get(acc.kernel, "trace_"), live_pmc, log)
+        cnt, src = (counters_for("%s:%d:full:%d" % (args.config, spp, args.kernel), KERNEL_SYMBOL.get(acc.kernel, ("trace_",)), live_pmc, log)
                     if world == 1 else (None, "counters are collected at N = 1 only"))
         roof = roofline_of(acc, cfg, cnt, src)
         line = {

@@ -179,7 +179,7 @@ struct PackedScene {
     std::vector<SphereX> spheres; std::vector<uint32_t> sphere_id;
     std::vector<PlaneX> planes; std::vector<TriX> tris;
     std::vector<MaterialX> mats;
-    std::vector<float4> sph32, tri32, leaf32;
+    std::vector<float4> sph32, tri32, leaf32, leaf_cr;
     std::vector<uint32_t> tri_fidx;
     std::vector<uint8_t> tri_rec_free_axis;          // per tree record (leaf order): the axis its footprint is unbounded along
     BvhBuild bvh;
@@ -365,6 +365,13 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
         const uint32_t p = bvh.prims[k];
         leaf32[k] = make_float4(fx[p], fy[p], fz[p], fw[p]);
     }
+    // the spheres kernel's leaf record {c - centre, |r|} (sphere.rs:24 squares the radius: its sign does not matter);
+    // |r| rounded up, which only adds candidates
+    p.leaf_cr.assign(bvh.prims.size(), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t k = 0; k < bvh.prims.size(); ++k) {
+        const uint32_t q = bvh.prims[k];
+        p.leaf_cr[k] = make_float4(fx[q], fy[q], fz[q], round_up_f32(std::fabs(scene->objects[sphere_id[q]].geom[3])));
+    }
 
     return RTX_OK;
 }
@@ -393,6 +400,7 @@ int32_t upload_packed(RtxSceneHandle_ *h, const PackedScene &p)
     if (!rc) rc = upload_vec(h, p.bvh4.nodes, &h->sv.bvh_nodes);
     if (!rc) rc = upload_vec(h, p.bvh.prims, &h->sv.bvh_prims);
     if (!rc) rc = upload_vec(h, p.leaf32, &h->sv.bvh_leaf_f32);
+    if (!rc) rc = upload_vec(h, p.leaf_cr, &h->sv.bvh_leaf_cr);
     if (!rc) rc = upload_vec(h, p.spheres, &h->sv.spheres);
     if (!rc) rc = upload_vec(h, p.sphere_id, &h->sv.sphere_id);
     if (!rc) rc = upload_vec(h, p.planes, &h->sv.planes);
@@ -701,8 +709,13 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (batch < spp) {
         if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
     }
+    // a tree without triangle leaves runs the spheres kernel (f32-only loop, more waves per SIMD; RTX_HIP_BVH_CLASSIC=1: the
+    // general lock-step kernel, for A/B runs)
+    const bool spheres_kernel = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0 &&
+                                !std::getenv("RTX_HIP_BVH_CLASSIC");
     if (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) {
-        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, bvh_spill_bytes(h->sv, h->n_cus))) return rc;
+        const size_t need = spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus) : bvh_spill_bytes(h->sv, h->n_cus);
+        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
     }
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
@@ -748,8 +761,12 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
                                                    reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
-                                           reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            if (spheres_kernel)
+                RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                                       reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            else
+                RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                               reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,

@@ -41,6 +41,7 @@ struct SceneView {
     const Bvh4Node *bvh_nodes;                 // 4-wide nodes, 128 B each; node 0 is the root
     const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
     const float4   *bvh_leaf_f32;              // per sphere leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
+    const float4   *bvh_leaf_cr;               // the same entries as {c - centre, |r|} (rounded up): the spheres kernel's record
     uint32_t        n_bvh_nodes;
     uint32_t        bvh_root;                  // where a traversal starts: 0, or kBvhFlatNode when node 0 is a footprint node
     uint32_t        bvh_depth;

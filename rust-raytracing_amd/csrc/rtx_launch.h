@@ -28,6 +28,14 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
                             double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                             hipStream_t stream);
 
+// RTX_KERNEL_BVH for trees that hold spheres only (rtx_bvh_spheres.hip): an f32-only traversal loop with conservative
+// distance bounds, the exact tests after the walk, 5 waves per SIMD.  spill: bvh_spheres_spill_bytes() bytes (may be 0).
+uint32_t bvh_spheres_spill_entries(const SceneView &sv);
+size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
+hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                    double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
+                                    hipStream_t stream);
+
 // The same traversal scheduled as a per-lane state machine (rtx_bvh_regroup.hip): lanes that finished their traversal
 // wait until enough of them can shade together instead of the whole wave waiting for its longest traversal.
 hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,

@@ -280,6 +280,159 @@ __device__ __forceinline__ void bvh_step(const float4 *__restrict__ nodes, const
     }
 }
 
+// ---- spheres-only trees: a traversal loop without f64 -----------------------------------------------------------------
+// bvh_step above interleaves the exact f64 tests with the walk (every 4th step) because its pruning bound is the exact
+// winner's distance.  For spheres an f32 evaluation bounds the hit distance tightly from both sides when it is done
+// relative to the RAY ORIGIN (the sweep filter's expanded form cancels |c|^2 ~ M^2 against itself: its error 24uM^2 is
+// the size of r^2 for the small spheres of C2; here the cancellation is over |l| <= r):
+//     o = c - p        beta = o.d        l = o - beta d        Delta = r^2 - |l|^2        t = beta - sqrt(Delta)
+// (|d| = 1; sphere.rs:22-29 in closest-approach form: Delta is a quarter of the reference's discriminant.)  With
+// u = 2^-24, every input rounded once to f32 (c and p relative to the scene centre, |c| + r + |p| <= M) and one
+// rounding per operation:   |o^ - o| <= 3uM per component,   |beta^ - beta| <= 16uM,   |l^ - l| <= 24uM per component,
+//     |Delta^ - Delta| <= 84uM|l| + 1728u^2M^2 + 4u(|l|^2 + r^2)  <=  G := 128uM r + 8192u^2M^2      whenever |l| <= r + 43uM,
+// which holds for every sphere the reference reports (|l| < r) and whenever Delta^ > G.  Hence
+//     * a sphere the reference can report has Delta^ + G >= 0            -> the leaf filter (conservative)
+//     * Delta^ - G > 0 and t_lo > K  =>  the reference DOES report it     -> a certain hit
+//     * t_lo = beta^ - sqrt(Delta^ + G) - K  <=  t  <=  beta^ - sqrt(Delta^ - G) + K = t_hi,   K = 24uM
+// (K: beta's 16uM, the roundings of these few operations, the hardware sqrt's 1 ulp via the (1 +- 2^-21) factors, and
+// the reference's own f64 roundings, ~1e-15 M).  Boxes are pruned against best_up = min t_hi over the certain hits --
+// pure f32 -- and only candidates that can still be the winner (t_lo <= best_up) reach the exact f64 test, once, after
+// the walk.  The winner W is never lost: its boxes have an entry distance <= t_W <= best_up, it passes the filter, and
+// t_lo(W) <= t_W <= best_up.  The loop then holds no f64 value.
+struct SphereRay { float px, py, pz, dx, dy, dz, Kg, c0, K; };     // p relative to the scene centre; Kg = 128uM, c0 = 8192u^2M^2
+constexpr int kSphQueue = 4;                 // live candidates per lane: {local sphere index, t_lo}; more than 4 at once
+                                             // (coincident spheres) -> the segment tests every sphere exactly
+
+__device__ __forceinline__ void sphere_ray_from(const SceneView &sv, V3 pos, V3 dir, SphereRay &f)
+{
+    const double px = pos.x - sv.sphere_center[0], py = pos.y - sv.sphere_center[1], pz = pos.z - sv.sphere_center[2];
+    const double M = sv.sphere_cmax + sqrt(px * px + py * py + pz * pz);
+    f.px = (float)px; f.py = (float)py; f.pz = (float)pz;
+    f.dx = (float)dir.x; f.dy = (float)dir.y; f.dz = (float)dir.z;
+    if (!(M < 1.0e14) || !(M > 1.0e-12)) {             // outside the range the bounds were derived for: every sphere of a
+        f.px = f.py = f.pz = f.dx = f.dy = f.dz = 0.0f;   // visited leaf is a candidate, none is certain, t_lo = -inf
+        f.Kg = 0.0f; f.c0 = __builtin_inff(); f.K = 0.0f;
+        return;
+    }
+    const double u = 1.0 / 16777216.0;
+    f.Kg = __double2float_ru(128.0 * u * M);
+    f.c0 = __double2float_ru(8192.0 * u * u * M * M);
+    f.K = __double2float_ru(24.0 * u * M);
+}
+
+template <int STACK, bool SPILL, class RAY>
+__device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ nodes, const float4 *__restrict__ leaf_f32,
+                                                     const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
+                                                     uint32_t root, uint32_t *lds_stack, uint32_t *lds_q,
+                                                     uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                     size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
+                                                     uint32_t &nbox, uint32_t &nleaf)
+{
+    uint32_t sp = 0;
+    uint32_t node = root;
+    while (node != kNone) {
+        const float4 *np = nodes + 8 * (size_t)node;
+        float4 ca[4], cb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+        float tc[4];
+        uint32_t lnk[4], cnt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+            lnk[c] = __float_as_uint(ca[c].w);
+            cnt[c] = __float_as_uint(cb[c].w);
+        }
+        nbox += 4;
+        uint32_t leafmask = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (tc[c] < __builtin_inff() && cnt[c] - 1u < 0xFFFFu) leafmask |= 1u << c;              // a sphere leaf the ray enters
+        while (leafmask != 0u) {
+            const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
+            leafmask &= leafmask - 1u;
+            const uint32_t first = c == 0 ? lnk[0] : (c == 1 ? lnk[1] : (c == 2 ? lnk[2] : lnk[3]));
+            const uint32_t n = (c == 0 ? cnt[0] : (c == 1 ? cnt[1] : (c == 2 ? cnt[2] : cnt[3]))) & 0xFFFFu;
+            for (uint32_t k = 0; k < n; ++k) {
+                const float4 rec = leaf_f32[first + k];                              // {c - centre, r}
+                const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+                const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+                const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
+                const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+                const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+                const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+                const float Dp = Dl + G;
+                if (Dp >= 0.0f) {                                                     // the exact test cannot be excluded
+                    const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+                    const float Dm = Dl - G;
+                    // Delta > 0 for certain: t <= t_hi.  t_hi < 0 (the origin is inside the sphere or past it): the reference's
+                    // near root is negative and closest_object drops it (scene.rs:249) -- not a candidate at all
+                    const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+                    if (tlo <= best_up && !(thi < 0.0f)) {                            // (else it cannot be the winner)
+                        if (tlo > sr.K) best_up = fminf(best_up, thi);                // certainly reported: bounds the winner's distance
+                        if (qcnt == (uint32_t)kSphQueue) {                            // drop the entries a later certain hit has overtaken
+                            uint32_t w = 0;
+#pragma unroll
+                            for (int e = 0; e < kSphQueue; ++e) {
+                                const uint32_t ie = lds_q[(size_t)e * kBvhThreads + tid];
+                                const uint32_t te = lds_q[(size_t)(kSphQueue + e) * kBvhThreads + tid];
+                                if (__uint_as_float(te) <= best_up) {
+                                    lds_q[(size_t)w * kBvhThreads + tid] = ie;
+                                    lds_q[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                                    w += 1;
+                                }
+                            }
+                            qcnt = w;
+                        }
+                        if (qcnt == (uint32_t)kSphQueue) overflow = true;             // (the segment then tests every sphere exactly)
+                        else {
+                            lds_q[(size_t)qcnt * kBvhThreads + tid] = leaf_prims[first + k];
+                            lds_q[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                            qcnt += 1;
+                        }
+                    }
+                }
+            }
+            nleaf += n;
+        }
+        // interior children still in reach, nearest first (as bvh_step)
+        float key[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) key[c] = (cnt[c] == 0u && tc[c] <= best_up) ? tc[c] : __builtin_inff();
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
+        RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+        const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                               (key[3] < __builtin_inff() ? 1u : 0u);
+        if (sp + 3u <= (uint32_t)STACK) {
+#pragma unroll
+            for (uint32_t i = 1; i <= 3; ++i) {
+                const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;       // (row STACK = the sink)
+                lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
+            }
+            sp += npush;
+        } else {
+#define RTX_PUSH(v)                                                                                      \
+            {                                                                                            \
+                if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
+                else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                \
+                    spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;         \
+                } else overflow = true;                                                                  \
+            }
+            if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+            if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+            if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
+        }
+        node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+        if (node == kNone && sp != 0u) {
+            sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
+            node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                    : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+        }
+    }
+}
+
 // A whole traversal of one lane's segment: steps until the stack is empty, the queued candidates' exact f64 tests
 // every 4th step (and at the end) for all lanes together, so their cost is not paid per (step, child, shape) under
 // divergence -- the pruning bound lags by at most 4 steps, which only costs visits.

@@ -262,6 +262,59 @@ def test_axis_aligned_mesh_stays_inside_the_tree(gpu, oracle):
     assert int((np.abs(ex - ref).max(axis=2) > ATOL).sum()) <= 0.004 * w * h and ref.mean() > 0.01
 
 
+def test_spheres_kernel_paths(gpu, oracle):
+    """trace_bvh_spheres_kernel (RTX_KERNEL_BVH on a tree without triangle leaves: the f32-only traversal loop with
+    conservative distance bounds, exact tests after the walk) against the exhaustive f64 kernel bit for bit, on the paths
+    C2 does not reach: a tree deep enough for the HBM stack column, origins far outside the scene (f64 slab walk) and
+    beyond any walk (every sphere tested), axis-parallel rays, more coincident candidates than the 4-entry queue holds,
+    nested shells (every shell a certain hit, the nearest wins), and spheres whose radius is at the f32 resolution of
+    their centre (no certain hit exists: the bounds only ever add candidates)."""
+    import torch
+    from rust_raytracing_amd import scenes
+
+    def both(objs, cam, w=64, h=36, spp=2, **cfg):
+        out = []
+        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_EXACT):
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            hnd.close()
+            out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+        return out[0]
+
+    deep = scenes.random_spheres(300000, 11)
+    st = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), deep))
+    assert st["flags"] == 1 and st["stack_bound"] > 30                      # 3 * depth + 2 exceeds the LDS stack
+    img, segs, exact = both(deep, scenes.CAMERA)
+    assert img.mean() > 0.01 and exact < 8 * segs, (exact, segs)              # (no exhaustive fallback: about one exact test per segment)
+    c2 = scenes.random_spheres(10000, 1)
+    for cam in (((-400.0, 30.0, 10.0), (1.0, -0.05, 0.0), 0.5),             # outside origin_limit: the f64 slab walk
+                ((-3.0e12, 0.0, 0.0), (1.0, 0.0, 0.0), 1e-10),              # beyond it: every sphere, exactly
+                ((60.0, 0.0, 0.0), (0.0, 0.0, 1.0), 1.2),                   # inside the cloud
+                ((60.0, -80.0, 0.0), (0.0, 1.0, 0.0), 1e-9)):               # (almost) axis-parallel rays
+        img, segs, exact = both(c2, cam, focal_offset=0.0, non_focal_offset=0.0)
+    # 9 coincident spheres in front of everything: 9 live candidates > kSphQueue -> the segment's exhaustive fallback;
+    # first in scene order wins (scene.rs:250)
+    co = scenes.light_every(scenes.compact(scenes.random_spheres(300, 5)))
+    co["geom"][20:29] = (3.0, 0.1, 0.05, 0.8, 0, 0, 0, 0, 0)
+    co["emission_color"][20:29] = np.linspace(0.1, 0.9, 9)[:, None]
+    co["base_color"][20:29] = 0.0
+    img, segs, exact = both(co, scenes.CAMERA)
+    ref = oracle_render(oracle, co, 64, 36, rays_per_pixel=2, seed=42)
+    assert max_abs_diff(img, ref) <= ATOL and exact > 50 * segs / 10         # the fallback did run
+    shells = scenes.three_spheres()[[0] * 12].copy()
+    for k in range(12):
+        shells[k]["geom"][:4] = (8.0, 0.0, 0.0, 0.5 + 0.25 * k)
+        shells[k]["emission_color"] = (0.1 * k, 1.0 - 0.08 * k, 0.5); shells[k]["base_color"] = 0.0
+    img, segs, exact = both(shells[::-1].copy(), scenes.CAMERA)
+    assert max_abs_diff(img, oracle_render(oracle, shells[::-1].copy(), 64, 36, rays_per_pixel=2, seed=42)) <= ATOL
+    tiny = scenes.random_spheres(2000, 17)
+    tiny["geom"][:, 3] *= 2e-5                                               # r ~ 1e-5 at |c| ~ 100: r is 1-2 ulp(f32) of the centre
+    tiny["geom"][:, 0] = 10.0 + (tiny["geom"][:, 0] - 10.0) * 1e-3            # a thin slab the rays must cross
+    both(tiny, scenes.CAMERA, w=128, h=72)
+
+
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
     """Spheres + triangles + a plane under one root; camera variants: inside the cloud looking along -z (rays nearly
     parallel to the footprints' unbounded axis), exactly axis-parallel directions (0 * inf in the slab test), and far
