@@ -179,7 +179,7 @@ struct PackedScene {
     std::vector<SphereX> spheres; std::vector<uint32_t> sphere_id;
     std::vector<PlaneX> planes; std::vector<TriX> tris;
     std::vector<MaterialX> mats;
-    std::vector<float4> sph32, tri32, leaf32, leaf_cr;
+    std::vector<float4> sph32, tri32, leaf32, leaf_cr, tri_geo;
     std::vector<uint32_t> tri_fidx;
     std::vector<uint8_t> tri_rec_free_axis;          // per tree record (leaf order): the axis its footprint is unbounded along
     BvhBuild bvh;
@@ -252,7 +252,7 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     // Triangles solved in (x, y) also get a real filter record; the others a pass-all record (their leaf box already
     // says "the ray passes over the footprint").  An ill-conditioned projection (the rounding of a, b could report a
     // hit outside the footprint) keeps a triangle outside the tree: tested for every segment.
-    struct TriRec { float4 A, B; uint32_t tri; };
+    struct TriRec { float4 A, B, g0, g1; uint32_t tri; };
     std::vector<TriRec> tree_recs[3], always_recs;                     // tree_recs[f]: the elimination does not read axis f
     std::vector<BvhBox> tri_boxes[3];
     double tri_extent = 0.0;
@@ -277,8 +277,15 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
         TriRec rec;
         rec.A = make_float4(0.f, 0.f, 0.f, 0.f);                       // "always a candidate"
         rec.B = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec.g0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec.g1 = make_float4(0.f, 0.f, NAN, 0.f);                      // n.v0 = NaN: no f32 certain-hit bounds for this record
         rec.tri = (uint32_t)k;
         if (in_tree && free_axis == 2) {
+            // (a, b) = M (q - v0)_xy with M the inverse of [r s] in the (x, y) rows: the solution Triangle::contains' elimination
+            // computes (triangle.rs:55-100); n.v0 in absolute coordinates for the cull test (triangle.rs:115)
+            const double m00 = s1 / det, m01 = -s0 / det, m10 = -r1 / det, m11 = r0 / det;
+            rec.g0 = make_float4((float)v[0][0], (float)v[0][1], (float)m00, (float)m01);
+            rec.g1 = make_float4((float)m10, (float)m11, (float)kabs, 0.f);
             const double xlo = std::fmin(v[0][0], std::fmin(v[1][0], v[2][0])), xhi = std::fmax(v[0][0], std::fmax(v[1][0], v[2][0]));
             const double ylo = std::fmin(v[0][1], std::fmin(v[1][1], v[2][1])), yhi = std::fmax(v[0][1], std::fmax(v[1][1], v[2][1]));
             const double kc = t.n.x * v[0][0] + t.n.y * v[0][1] + t.n.z * v[0][2];
@@ -328,6 +335,7 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
         for (uint32_t idx : bvh.tri_order) {
             const TriRec &r = all_tree[idx];
             tri32.push_back(r.A); tri32.push_back(r.B); tri_fidx.push_back(r.tri); p.tri_rec_free_axis.push_back(all_free[idx]);
+            p.tri_geo.push_back(r.g0); p.tri_geo.push_back(r.g1);
         }
         n_in_tree = bvh.tri_order.size();
     } else {                                    // (the build was refused: coordinates too large for the f32 slab test)
@@ -354,7 +362,8 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     p.sv.bvh_root = bvh4.root;
     p.sv.bvh_origin_limit = (float)bvh.origin_limit;
     p.sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
-    p.sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u);
+    p.sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u) |
+                     (bvh.has_tris && !bvh.has_spheres && tree_recs[1].empty() && tree_recs[0].empty() ? 4u : 0u);
     if (std::getenv("RTX_HIP_DEBUG"))
         std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree: %zu xy / %zu xz / %zu yz footprints, %zu tested per segment), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
                      spheres.size(), tris.size(), n_in_tree, tree_recs[2].size(), tree_recs[1].size(), tree_recs[0].size(),
@@ -409,6 +418,7 @@ int32_t upload_packed(RtxSceneHandle_ *h, const PackedScene &p)
     if (!rc) rc = upload_vec(h, p.sph32, &h->sv.sphere_f32);
     if (!rc) rc = upload_vec(h, p.tri32, &h->sv.tri_f32);
     if (!rc) rc = upload_vec(h, p.tri_fidx, &h->sv.tri_fidx);
+    if (!rc) rc = upload_vec(h, p.tri_geo, &h->sv.tri_geo);
     if (rc) {
         for (void *d : h->scene_allocs) (void)hipFree(d);
         h->scene_allocs.swap(old_allocs);
@@ -713,8 +723,12 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     // general lock-step kernel, for A/B runs)
     const bool spheres_kernel = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0 &&
                                 !std::getenv("RTX_HIP_BVH_CLASSIC");
+    // the regrouping schedule on a tree with triangle leaves runs the mesh kernel (f32-only traversal step;
+    // RTX_HIP_BVH_CLASSIC=1: trace_bvh_regroup_kernel)
+    const bool mesh_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 2u) != 0u && !std::getenv("RTX_HIP_BVH_CLASSIC");
     if (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) {
-        const size_t need = spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus) : bvh_spill_bytes(h->sv, h->n_cus);
+        const size_t need = spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus)
+                            : mesh_kernel ? bvh_mesh_spill_bytes(h->sv, h->n_cus) : bvh_spill_bytes(h->sv, h->n_cus);
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
     }
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
@@ -757,8 +771,12 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            RTX_HIP_CHECK(launch_trace_bvh_regroup(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
-                                                   reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            if (mesh_kernel)
+                RTX_HIP_CHECK(launch_trace_bvh_mesh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                                    reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            else
+                RTX_HIP_CHECK(launch_trace_bvh_regroup(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                                       reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             if (spheres_kernel)

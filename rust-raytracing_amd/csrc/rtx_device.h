@@ -30,6 +30,9 @@ struct SceneView {
     // the (x, y) projection Triangle::contains solves in (triangle.rs:55-100); tri_fidx maps a record to tris[]
     const float4   *tri_f32;
     const uint32_t *tri_fidx;
+    const float4   *tri_geo;                   // per TREE record (the first n_tri_tree), 2 x float4: {v0.xy - centre, m00, m01} {m10, m11, n.v0, -}
+                                               // with (a, b) = M (q - v0)_xy: the f32 certain-hit bounds of rtx_bvh_mesh.hip; n.v0 = NaN
+                                               // marks a triangle the bounds do not cover (footprint in another plane)
     uint32_t        n_tri_filter;
     uint32_t        pad0_;
     double          tri_extent;                // max over filtered triangles of |vertex - centre|_inf
@@ -47,7 +50,8 @@ struct SceneView {
     uint32_t        bvh_depth;
     uint32_t        pad2_;
     float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
-    uint32_t        bvh_flags;                 // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
+    uint32_t        bvh_flags;                 // bit 2: the tree holds nothing but (x, y)-footprint triangles (every node is a footprint node);
+                                               // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
     uint32_t        n_tri_tree;                // triangle filter records [0, n_tri_tree) are in leaf order (a triangle leaf's link
     float           bvh_inv_max;               // indexes them); [n_tri_tree, n_tri_filter) are outside the tree.  bvh_inv_max: rtx_traverse.h
 };

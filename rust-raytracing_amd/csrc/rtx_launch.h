@@ -42,6 +42,14 @@ hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, 
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill,
                                     int n_cus, hipStream_t stream);
 
+// RTX_KERNEL_BVH_REGROUP for trees that hold triangles (rtx_bvh_mesh.hip): the regrouping schedule with an f32-only
+// traversal step (certain-hit bounds, exact tests in the f64 phase).  spill: bvh_mesh_spill_bytes() bytes (may be 0).
+uint32_t bvh_mesh_spill_entries(const SceneView &sv);
+size_t bvh_mesh_spill_bytes(const SceneView &sv, int n_cus);
+hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                 double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
+                                 hipStream_t stream);
+
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in sample order).
 // samples: rv.n_rays 32-byte records in ray-queue order (store_sample, rtx_device.h); per_sample = queue slots
 // of one sample (npix, or the padded 8x8-tile grid when rv.tiles_x != 0).  first: acc starts from zero.

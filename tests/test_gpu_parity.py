@@ -315,6 +315,54 @@ def test_spheres_kernel_paths(gpu, oracle):
     both(tiny, scenes.CAMERA, w=128, h=72)
 
 
+def test_mesh_kernel_paths(gpu, oracle):
+    """trace_bvh_mesh_kernel (RTX_KERNEL_BVH_REGROUP on a tree with triangle leaves: f32-only traversal step with certain-hit
+    bounds, exact tests in the f64 phase, self-hit pre-test) against the exhaustive f64 kernel bit for bit on the paths
+    the benchmark meshes rarely take: more live candidates than the 6-entry queue holds (coincident triangles: the lane
+    asks for a flush and resumes at the same node; first in scene order wins, scene.rs:250), origins far outside the
+    scene (f64 slab walk, inline flushes) and beyond any walk, a pure (x, y)-footprint tree (the PLAIN variant) and a
+    joint tree with spheres and faces solved in other planes, needle / edge-on triangles the bounds can never certify."""
+    import torch
+    from rust_raytracing_amd import scenes
+
+    def both(objs, cam, w=64, h=36, spp=2, **cfg):
+        out = []
+        for kern in (gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_EXACT):
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            hnd.close()
+            out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+        return out[0]
+
+    mesh = scenes.light_every(scenes.compact(scenes.random_triangles(4000, 6), k=0.05, x0=5.0))
+    st = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), mesh))
+    assert st["flags"] == 2 + 4 and st["tri_other_footprints"] == 0 and st["flat_nodes"] == st["wide_nodes"]   # the PLAIN variant
+    co = mesh.copy()
+    co["geom"][100:114] = (3.0, -0.6, -0.5, 3.0, 0.7, -0.4, 3.1, 0.0, 0.8)        # 14 coincident triangles in front of the mesh
+    co["emission_color"][100:114] = np.linspace(0.1, 0.9, 14)[:, None]
+    co["base_color"][100:114] = 0.0
+    img, segs, exact = both(co, scenes.CAMERA)
+    assert max_abs_diff(img, oracle_render(oracle, co, 64, 36, rays_per_pixel=2, seed=42)) <= ATOL
+    assert exact < 40 * segs and img.mean() > 0.01                            # flushes, not the exhaustive fallback (4000 per segment)
+    for cam in (((-300.0, 2.0, 1.0), (1.0, 0.0, 0.0), 0.05),                  # outside origin_limit: the f64 slab walk
+                ((-3.0e12, 0.0, 0.0), (1.0, 0.0, 0.0), 1e-11),                # beyond it: every shape, exactly
+                ((5.5, 0.0, 9.0), (0.0, 0.0, -1.0), 1.0),                     # straight down the footprints' unbounded axis
+                ((5.5, 0.1, 0.0), (0.2, 1.0, 0.1), 1.4)):                     # from inside the mesh
+        both(co, cam, focal_offset=0.0, non_focal_offset=0.0)
+    far = both(co, ((-300.0, 2.0, 1.0), (1.0, 0.0, 0.0), 0.05))               # with the default jitter as well
+    joint = np.concatenate([scenes.compact(scenes.random_spheres(300, 3), k=0.06, x0=5.0), co[:1500], scenes.axis_aligned_mesh(60, x0=4.0, span=2.0)])
+    stj = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), joint))
+    assert stj["flags"] == 3 and stj["tri_other_footprints"] > 100
+    img, segs, exact = both(joint, scenes.CAMERA)
+    both(joint, ((-300.0, 2.0, 1.0), (1.0, 0.0, 0.0), 0.05))
+    needles = mesh.copy()
+    needles["geom"][:, 6:9] = needles["geom"][:, 0:3] + (needles["geom"][:, 3:6] - needles["geom"][:, 0:3]) * 0.5 + 1e-5   # area ~ 1e-5
+    needles["geom"][::2, 2] = needles["geom"][::2, 5] = needles["geom"][::2, 8]                                             # every other one edge-on in z
+    both(needles, scenes.CAMERA, w=96, h=54)
+
+
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
     """Spheres + triangles + a plane under one root; camera variants: inside the cloud looking along -z (rays nearly
     parallel to the footprints' unbounded axis), exactly axis-parallel directions (0 * inf in the slab test), and far
