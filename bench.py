@@ -65,10 +65,11 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                 3: "trace_mixed_kernel + verify",
                 4: "flat 4-wide BVH, lock-step waves (trace_bvh_spheres_kernel: f32-only traversal loop, exact f64 tests after the "
                    "walk; trace_bvh_kernel when the tree holds triangles)",
-                5: "flat 4-wide BVH, regrouping schedule (trace_bvh_regroup_kernel)"}
+                5: "flat 4-wide BVH, regrouping schedule (trace_bvh_mesh_kernel: f32-only traversal step, exact f64 tests in the "
+                   "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)"}
 # substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
 KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
-                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel",)}
+                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel")}
 # lane-op prices of the algorithmic counts (what the chosen algorithm needs at least; f64 instructions issue at half rate
 # and count double).  box test: 6 fma + 9 min/max + 2 mul + 2 cmp; sphere filter: 7 fma + 1 sub; triangle filter: 16;
 # exact sphere test (sphere.rs:19-30): 17 f64 add/mul + sqrt + div (~14 f64 instructions each) = 45 f64 -> 90; exact
@@ -473,7 +474,7 @@ def main():
             hnd.close()
             rays = n_rows * oc["w"] * s * 2
             leg = "%s:%d:%s:0" % (name, s, "band" if band else "full")
-            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, ("trace_",)), live_pmc and name in ("C3", "C5"), log)
+            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, ("trace_",)), live_pmc, log)
             others.append({
                 "config": name, "workload": "%s, %s at %d spp (the config names %d spp; Mrays/s is a rate)" % (
                     oc["name"], "the interleaved row band rank 0 of 8 owns (%d rows)" % n_rows if band else "full frame", s, oc["spp"]),
