@@ -17,9 +17,11 @@
 //     resumes its walk at the same node; the exhaustive sweep remains only for a single node that yields more live
 //     candidates than the queue has entries (coincident shapes).
 //
-// With the f64 tests out of the loop its registers are free for memory-level parallelism, which is what a mesh needs:
-// the regrouped walk spends 3/4 of its wave cycles waiting on dependent fetches (profiles/: SQ_WAIT_ANY / SQ_WAVE_CYCLES
-// = 0.73 on C3, 0.76 on C5).  The step therefore requests the NEXT node before it reads the current node's leaf records.
+// Measured (same box): C3 130 -> 144 Mrays/s, C5 band 34.5 -> 39.8.  The mesh walk is latency-bound (SQ_WAIT_ANY /
+// SQ_WAVE_CYCLES 0.73 / 0.76 with round 1's step, 0.66 / 0.68 with this one), so two ways to put more fetches in flight
+// were tried and dropped: requesting the NEXT node before reading the current node's leaf records
+// (-DRTX_MESH_PIPE=1: needs 32 more registers than 4 waves per SIMD leave; at 3 or 2 waves per SIMD it only breaks even) and
+// 5 or 6 waves per SIMD (-DRTX_MESH_WAVES: in-loop spill reloads).
 #include "rtx_launch.h"
 #include "rtx_traverse.h"
 
