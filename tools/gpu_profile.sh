@@ -26,7 +26,7 @@ PY
 export TMPDIR=/tmp
 cd /tmp
 echo "[gpu_profile] rocprofv3 --kernel-trace --stats of the same command"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-other-configs > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
 find $OUT/trace -name "*kernel_stats.csv" | head -3
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 head -8 "$f" | cut -c1-200
