@@ -45,6 +45,9 @@ if __name__ == "__main__":
     n += run("mixed 3k spheres + 30k triangles + 2 planes",
              np.concatenate([scenes.random_spheres(3000, 11), scenes.random_triangles(30000, 12), scenes.mixed_scene(0, 0, 2)]),
              int(960 * scale), int(540 * scale), 1, K)
+    aam = scenes.axis_aligned_mesh(4000, seed=9, span=80.0, x0=20.0)          # 48k cube faces: footprints in all three planes
+    n += run("axis-aligned mesh 48k faces + 2k spheres",
+             np.concatenate([aam, scenes.random_spheres(2000, 13)]), int(960 * scale), int(540 * scale), 1, K)
     if "c5" in sys.argv[2:]:                      # 1M triangles: the exhaustive kernel needs ~10 s per camera at this size
         n += run("C5 1M triangles", scenes.random_triangles(1000000, 3, box=2.0), int(480 * scale), int(270 * scale), 1,
                  [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP])
