@@ -66,10 +66,11 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                 4: "flat 4-wide BVH, lock-step waves (trace_bvh_spheres_kernel: f32-only traversal loop, exact f64 tests after the "
                    "walk; trace_bvh_kernel when the tree holds triangles)",
                 5: "flat 4-wide BVH, regrouping schedule (trace_bvh_mesh_kernel: f32-only traversal step, exact f64 tests in the "
-                   "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)"}
+                   "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)",
+                6: "wavefront form for pure meshes: wf_trace_kernel (f32-only walk, 6 waves/SIMD) + wf_shade_kernel (f64) per bounce level"}
 # substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
 KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
-                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel")}
+                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel"), 6: ("wf_trace_kernel",)}
 # lane-op prices of the algorithmic counts (what the chosen algorithm needs at least; f64 instructions issue at half rate
 # and count double).  box test: 6 fma + 9 min/max + 2 mul + 2 cmp; sphere filter: 7 fma + 1 sub; triangle filter: 16;
 # exact sphere test (sphere.rs:19-30): 17 f64 add/mul + sqrt + div (~14 f64 instructions each) = 45 f64 -> 90; exact
@@ -88,7 +89,7 @@ def parse():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json config benched as the primary workload")
     ap.add_argument("--spp", type=int, default=None, help="total rays per pixel (default: the config's own, 64 for C2)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: rays_per_pixel = spp * N (fixed rays per GPU); not the metric")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH lock-step, 5 BVH regroup")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH lock-step, 5 BVH regroup, 6 wavefront (pure meshes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds-sweep", action="store_true", help="skip the secondary measurement of the LDS sweep kernel")
     ap.add_argument("--no-other-configs", action="store_true", help="skip C3 / C4 band / C5 band at N = 1")

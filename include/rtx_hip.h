@@ -66,9 +66,13 @@ enum {
                               3-D sphere boxes; (x, y) footprints for triangles, which keeps the reference's phantom
                               hits), exact f64 leaf tests; planes and shapes outside the tree tested for every
                               segment; same bits as RTX_KERNEL_EXACT.  RtxStats.box_tests counts child boxes tested */
-    RTX_KERNEL_BVH_REGROUP = 5 /* RTX_KERNEL_BVH's tree and step under a different schedule: lanes whose traversal ended
+    RTX_KERNEL_BVH_REGROUP = 5, /* RTX_KERNEL_BVH's tree and step under a different schedule: lanes whose traversal ended
                               wait until enough of them can shade together, instead of every lane waiting for the
                               wave's longest traversal; pays off on large triangle meshes; same bits */
+    RTX_KERNEL_WAVEFRONT = 6   /* the same tree walked by a kernel of its own per bounce level (f32 only, many waves per SIMD),
+                              the f64 exact tests + ray_hit in a second kernel, the ray state structure-of-arrays in HBM
+                              between them; for trees that hold nothing but (x, y)-footprint triangles (a mesh), any other
+                              scene takes RTX_KERNEL_BVH_REGROUP; same bits */
 };
 
 /* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)

@@ -19,12 +19,12 @@ import math
 import numpy as np
 
 from . import abi
-from .abi import (OBJECT_DTYPE, RTX_KERNEL_AUTO, RTX_KERNEL_BVH, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH_REGROUP,
+from .abi import (OBJECT_DTYPE, RTX_KERNEL_WAVEFRONT, RTX_KERNEL_AUTO, RTX_KERNEL_BVH, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH_REGROUP,
                   RTX_PLANE, RTX_SPHERE, RTX_TRIANGLE, RtxError, load_library)
 
 __all__ = ["Vector3", "Material", "Sphere", "Plane", "Triangle", "Object", "Config", "Camera", "Scene",
            "SceneHandle", "RtxError", "device_count", "pack_objects", "OBJECT_DTYPE",
-           "RTX_KERNEL_AUTO", "RTX_KERNEL_EXACT", "RTX_KERNEL_MIXED", "RTX_KERNEL_MIXED_VERIFY", "RTX_KERNEL_BVH", "RTX_KERNEL_BVH_REGROUP", "debug_host_scene"]
+           "RTX_KERNEL_AUTO", "RTX_KERNEL_EXACT", "RTX_KERNEL_MIXED", "RTX_KERNEL_MIXED_VERIFY", "RTX_KERNEL_BVH", "RTX_KERNEL_BVH_REGROUP", "RTX_KERNEL_WAVEFRONT", "debug_host_scene"]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(HERE, "librtx_hip.so") 
 
 RTX_SPHERE, RTX_PLANE, RTX_TRIANGLE = 0, 1, 2
 RTX_KERNEL_AUTO, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH, RTX_KERNEL_BVH_REGROUP = 0, 1, 2, 3, 4, 5
+RTX_KERNEL_WAVEFRONT = 6
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)

@@ -81,6 +81,7 @@ struct RtxSceneHandle_ {
     double *tables = nullptr;   size_t tables_doubles = 0;
     double *h_tables = nullptr; size_t h_tables_doubles = 0;
     double *state = nullptr;    size_t state_bytes = 0;
+    void *wf_state = nullptr;   size_t wf_bytes = 0;       // the wavefront kernels' ray state
     Counters *counters = nullptr;
     unsigned long long *work_counter = nullptr;
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
@@ -131,7 +132,7 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
 
 int32_t check_config(const RtxConfig &cfg)
 {
-    if (cfg.kernel > RTX_KERNEL_BVH_REGROUP) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
+    if (cfg.kernel > RTX_KERNEL_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
     if (cfg.max_bounces == UINT64_MAX)       // max_bounces + 1 overflows in the reference (scene.rs:227)
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.max_bounces + 1 overflows");
     if (cfg.rays_per_pixel > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.rays_per_pixel exceeds 2^32-1");
@@ -158,6 +159,7 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->tables) (void)hipFree(h->tables);
     if (h->h_tables) (void)hipHostFree(h->h_tables);
     if (h->state) (void)hipFree(h->state);
+    if (h->wf_state) (void)hipFree(h->wf_state);
     if (h->counters) (void)hipFree(h->counters);
     if (h->work_counter) (void)hipFree(h->work_counter);
     if (h->d_sv) (void)hipFree(h->d_sv);
@@ -661,9 +663,11 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         }
     }
 
+    // the wavefront form exists for pure (x, y)-footprint triangle trees; any other scene takes the regrouping kernel
+    if (kernel == RTX_KERNEL_WAVEFRONT && (h->sv.bvh_flags & 4u) == 0u) kernel = RTX_KERNEL_BVH_REGROUP;
     // the BVH kernels' ray queue runs over 8x8 pixel tiles (a wave's 64 rays = one tile); a sample then has
     // tiles_x * tiles_y * 64 queue slots (the padding of partial tiles included), else npix
-    const bool tiled = (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) && !std::getenv("RTX_HIP_NO_TILES");
+    const bool tiled = (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP || kernel == RTX_KERNEL_WAVEFRONT) && !std::getenv("RTX_HIP_NO_TILES");
     const uint32_t tiles_x = tiled ? (width + 7u) / 8u : 0u;
     const uint64_t per_sample64 = tiled ? (uint64_t)tiles_x * ((n_rows + 7u) / 8u) * 64u : (uint64_t)npix;
     if (per_sample64 > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: more than 2^32 ray slots per sample");
@@ -671,7 +675,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     // samples per launch: all of them unless the sample planes would exceed the scratch cap (or 2^32 rays)
     uint64_t batch = spp;
     {
-        const uint64_t fit = scratch_cap_bytes() / (per_sample64 * 4 * sizeof(double));
+        // bytes per ray of a batch: the 32-byte sample record (+ the wavefront kernels' state, ~270 B)
+        const uint64_t per_ray = 4 * sizeof(double) + (kernel == RTX_KERNEL_WAVEFRONT ? wavefront_state_bytes(1u << 20, 1) >> 20 : 0);
+        const uint64_t fit = scratch_cap_bytes() / (per_sample64 * per_ray);
         const uint64_t fit32 = 0xFFFFFFF0ull / per_sample64;
         if (batch > fit) batch = fit ? fit : 1;
         if (batch > fit32) batch = fit32;
@@ -734,6 +740,10 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
+    if (kernel == RTX_KERNEL_WAVEFRONT) {
+        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, wavefront_spill_bytes(h->sv, h->n_cus))) return rc;
+        if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, wavefront_state_bytes(batch * per_sample64, wavefront_levels(h->sv)))) return rc;
+    }
 
     RowsView rv{};
     rv.width = width; rv.height = height;
@@ -769,6 +779,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
+        } else if (kernel == RTX_KERNEL_WAVEFRONT) {
+            RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
+                                                 reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             if (mesh_kernel)

@@ -50,6 +50,16 @@ hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, con
                                  double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                  hipStream_t stream);
 
+// RTX_KERNEL_WAVEFRONT (rtx_wavefront.hip): the path of a pure (x, y)-footprint triangle tree as generate / walk / shade
+// kernels per bounce level, the ray state in HBM.  state_mem: wavefront_state_bytes(rv.n_rays, ...) bytes; spill:
+// wavefront_spill_bytes() bytes (may be 0).  Enqueues everything on `stream`; synchronises it only when max_bounces + 1
+// exceeds 16 levels.
+size_t wavefront_state_bytes(uint64_t n_rays, uint32_t levels);
+uint32_t wavefront_levels(const SceneView &sv);
+size_t wavefront_spill_bytes(const SceneView &sv, int n_cus);
+hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                  double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream);
+
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in sample order).
 // samples: rv.n_rays 32-byte records in ray-queue order (store_sample, rtx_device.h); per_sample = queue slots
 // of one sample (npix, or the padded 8x8-tile grid when rv.tiles_x != 0).  first: acc starts from zero.

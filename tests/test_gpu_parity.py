@@ -32,7 +32,7 @@ def gpu(rtx):
 
 
 def _kernels(rtx):
-    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP]
+    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT]
 
 
 # ---- device arithmetic ---------------------------------------------------------------------------
@@ -321,19 +321,23 @@ def test_mesh_kernel_paths(gpu, oracle):
     the benchmark meshes rarely take: more live candidates than the 6-entry queue holds (coincident triangles: the lane
     asks for a flush and resumes at the same node; first in scene order wins, scene.rs:250), origins far outside the
     scene (f64 slab walk, inline flushes) and beyond any walk, a pure (x, y)-footprint tree (the PLAIN variant) and a
-    joint tree with spheres and faces solved in other planes, needle / edge-on triangles the bounds can never certify."""
+    joint tree with spheres and faces solved in other planes, needle / edge-on triangles the bounds can never certify.
+    RTX_KERNEL_WAVEFRONT (the same step as a kernel of its own per bounce level, exact tests + ray_hit in a second kernel,
+    ray state in HBM) runs beside it: on the pure mesh it is the wavefront form (incl. more bounce levels than one
+    host-side chunk of 16, and sample batches), on the joint scenes it resolves to the regrouping kernel."""
     import torch
     from rust_raytracing_amd import scenes
 
     def both(objs, cam, w=64, h=36, spp=2, **cfg):
         out = []
-        for kern in (gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_EXACT):
+        for kern in (gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_KERNEL_EXACT):
             hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
             hnd.close()
             out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
-        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+        for o in out[:-1]:
+            assert np.array_equal(o[0], out[-1][0]) and o[1] == out[-1][1]
         return out[0]
 
     mesh = scenes.light_every(scenes.compact(scenes.random_triangles(4000, 6), k=0.05, x0=5.0))
@@ -352,6 +356,15 @@ def test_mesh_kernel_paths(gpu, oracle):
                 ((5.5, 0.1, 0.0), (0.2, 1.0, 0.1), 1.4)):                     # from inside the mesh
         both(co, cam, focal_offset=0.0, non_focal_offset=0.0)
     far = both(co, ((-300.0, 2.0, 1.0), (1.0, 0.0, 0.0), 0.05))               # with the default jitter as well
+    bouncy = co.copy()
+    bouncy["base_color"] = 0.97; bouncy["emission_color"] *= 0.05              # paths survive: up to 41 / 1 segments per ray
+    both(bouncy, scenes.CAMERA, max_bounces=40)
+    both(bouncy, scenes.CAMERA, max_bounces=0)
+    os.environ["RTX_HIP_SCRATCH_MB"] = "1"                                     # 64 x 36 x 300 B per sample: one sample per batch
+    try:
+        both(co, scenes.CAMERA, spp=3)
+    finally:
+        del os.environ["RTX_HIP_SCRATCH_MB"]
     joint = np.concatenate([scenes.compact(scenes.random_spheres(300, 3), k=0.06, x0=5.0), co[:1500], scenes.axis_aligned_mesh(60, x0=4.0, span=2.0)])
     stj = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), joint))
     assert stj["flags"] == 3 and stj["tri_other_footprints"] > 100
