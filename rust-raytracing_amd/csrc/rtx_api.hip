@@ -280,22 +280,26 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
         rec.A = make_float4(0.f, 0.f, 0.f, 0.f);                       // "always a candidate"
         rec.B = make_float4(0.f, 0.f, 0.f, 0.f);
         rec.g0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        rec.g1 = make_float4(0.f, 0.f, NAN, 0.f);                      // n.v0 = NaN: no f32 certain-hit bounds for this record
+        rec.g1 = make_float4(0.f, 0.f, NAN, 0.f);                      // n.v0 = NaN: no f32 bounds for this record (outside the tree)
         rec.tri = (uint32_t)k;
-        if (in_tree && free_axis == 2) {
-            // (a, b) = M (q - v0)_xy with M the inverse of [r s] in the (x, y) rows: the solution Triangle::contains' elimination
-            // computes (triangle.rs:55-100); n.v0 in absolute coordinates for the cull test (triangle.rs:115)
+        if (in_tree) {
+            // (a, b) = M (q - v0)_uv with M the inverse of [r s] in the two rows Triangle::contains' elimination reads
+            // (triangle.rs:55-100; (u, v) = (x, y), (x, z) or (y, z)); n.v0 in absolute coordinates for the cull test
+            // (triangle.rs:115); the plane's code for tri_bounds (rtx_mesh_step.h)
             const double m00 = s1 / det, m01 = -s0 / det, m10 = -r1 / det, m11 = r0 / det;
-            rec.g0 = make_float4((float)v[0][0], (float)v[0][1], (float)m00, (float)m01);
-            rec.g1 = make_float4((float)m10, (float)m11, (float)kabs, 0.f);
+            const double kc = t.n.x * v[0][0] + t.n.y * v[0][1] + t.n.z * v[0][2];
+            rec.g0 = make_float4((float)v[0][a0], (float)v[0][a1], (float)m00, (float)m01);
+            rec.g1 = make_float4((float)m10, (float)m11, (float)kabs, (float)(2 - free_axis));
+            rec.A = make_float4((float)t.n.x, (float)t.n.y, (float)t.n.z, (float)kc);
+            rec.B = make_float4(0.f, 0.f, 1.0e30f, 1.0e30f);           // no (x, y) rectangle to test: every ray passes the footprint filter
+            for (int c = 0; c < 9; ++c) tri_extent = std::fmax(tri_extent, std::fabs(v[c / 3][c % 3]));
+        }
+        if (in_tree && free_axis == 2) {
             const double xlo = std::fmin(v[0][0], std::fmin(v[1][0], v[2][0])), xhi = std::fmax(v[0][0], std::fmax(v[1][0], v[2][0]));
             const double ylo = std::fmin(v[0][1], std::fmin(v[1][1], v[2][1])), yhi = std::fmax(v[0][1], std::fmax(v[1][1], v[2][1]));
-            const double kc = t.n.x * v[0][0] + t.n.y * v[0][1] + t.n.z * v[0][2];
             const double grow = 1.0 + 1.0 / 1048576.0;
-            rec.A = make_float4((float)t.n.x, (float)t.n.y, (float)t.n.z, (float)kc);
             rec.B = make_float4((float)(0.5 * (xlo + xhi)), (float)(0.5 * (ylo + yhi)),
                                 round_up_f32(0.5 * (xhi - xlo) * grow + 1e-30), round_up_f32(0.5 * (yhi - ylo) * grow + 1e-30));
-            for (int c = 0; c < 9; ++c) tri_extent = std::fmax(tri_extent, std::fabs(v[c / 3][c % 3]));
         }
         if (in_tree) { tree_recs[free_axis].push_back(rec); tri_boxes[free_axis].push_back(fp); }
         else always_recs.push_back(rec);

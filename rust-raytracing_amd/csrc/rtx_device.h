@@ -30,9 +30,9 @@ struct SceneView {
     // the (x, y) projection Triangle::contains solves in (triangle.rs:55-100); tri_fidx maps a record to tris[]
     const float4   *tri_f32;
     const uint32_t *tri_fidx;
-    const float4   *tri_geo;                   // per TREE record (the first n_tri_tree), 2 x float4: {v0.xy - centre, m00, m01} {m10, m11, n.v0, -}
-                                               // with (a, b) = M (q - v0)_xy: the f32 certain-hit bounds of rtx_bvh_mesh.hip; n.v0 = NaN
-                                               // marks a triangle the bounds do not cover (footprint in another plane)
+    const float4   *tri_geo;                   // per TREE record (the first n_tri_tree), 2 x float4: {v0.uv - centre, m00, m01} {m10, m11, n.v0, plane}
+                                               // with (a, b) = M (q - v0)_uv in the footprint's plane (0: xy, 1: xz, 2: yz): the f32
+                                               // certain-hit bounds of rtx_mesh_step.h
     uint32_t        n_tri_filter;
     uint32_t        pad0_;
     double          tri_extent;                // max over filtered triangles of |vertex - centre|_inf

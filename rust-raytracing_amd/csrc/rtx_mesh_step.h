@@ -12,10 +12,11 @@ constexpr int kMeshQueue = 6;                // live candidates per lane: {entry
 #define RTX_MESH_PIPE 0
 #endif
 constexpr bool kMeshPipe = RTX_MESH_PIPE != 0;    // request the next node before reading the current node's leaf records
-// f32 bounds of Triangle::distance for one tree triangle (footprint in the (x, y) plane).
+// f32 bounds of Triangle::distance for one tree triangle.
 //   A  = {n.xyz, n.(v0 - centre)}                       (the filter record's first half)
-//   g0 = {v0.x, v0.y (relative to the centre), m00, m01}     g1 = {m10, m11, n.v0 (absolute), -}
-// where (a, b) = M (q - v0)_xy solves a r + b s = q - v0 in the rows Triangle::contains reads (triangle.rs:55-100).
+//   g0 = {v0.u, v0.v (relative to the centre), m00, m01}     g1 = {m10, m11, n.v0 (absolute), plane}
+// where (u, v) are the two rows Triangle::contains reads -- plane 0: (x, y), 1: (x, z), 2: (y, z) -- and
+// (a, b) = M (q - v0)_uv solves a r + b s = q - v0 in those rows (triangle.rs:55-100).
 // With u = 2^-24 and S >= every coordinate magnitude relative to the centre (tri_filter_from_ray's S):
 //   dn = n.d        |dn^ - dn| <= 8u             nv = n.(v0 - p)      |nv^ - nv| <= 16uS
 //   t = |nv / dn|  in  [ (|nv^| - 16uS)+ / (|dn^| + 8u),  (|nv^| + 16uS) / (|dn^| - 8u) ]        (the latter needs |dn^| > 8u)
@@ -40,9 +41,12 @@ __device__ __forceinline__ float tri_bounds(const float4 A, const float4 g0, con
         const float th = (N + e_nv) / (D - e_dn) * (1.0f + 4.0f * u);
         const bool cull_ok = (g1.z - dn) > 2.0f * u * __builtin_fabsf(g1.z) + 2.0f * e_dn;       // n.(v0 - dir) >= 0 for certain (triangle.rs:115)
         const float tm = 0.5f * (tlo + th), ht = 0.5f * (th - tlo) * (1.0f + 4.0f * u) + u * th;
-        const float qx = __builtin_fmaf(f.dx, tm, -f.npx), qy = __builtin_fmaf(f.dy, tm, -f.npy);
+        // the two coordinates Triangle::contains reads: g1.w = 0: (x, y), 1: (x, z), 2: (y, z)
+        const float du = g1.w == 2.0f ? f.dy : f.dx, pu = g1.w == 2.0f ? f.npy : f.npx;
+        const float dv = g1.w == 0.0f ? f.dy : f.dz, pv = g1.w == 0.0f ? f.npy : f.npz;
+        const float qx = __builtin_fmaf(du, tm, -pu), qy = __builtin_fmaf(dv, tm, -pv);
         const float eq0 = 6.0f * u * (S + th) + 2.0f * u * S;
-        const float ewx = __builtin_fmaf(__builtin_fabsf(f.dx), ht, eq0), ewy = __builtin_fmaf(__builtin_fabsf(f.dy), ht, eq0);
+        const float ewx = __builtin_fmaf(__builtin_fabsf(du), ht, eq0), ewy = __builtin_fmaf(__builtin_fabsf(dv), ht, eq0);
         const float wx = qx - g0.x, wy = qy - g0.y;
         const float a = __builtin_fmaf(g0.z, wx, g0.w * wy), b = __builtin_fmaf(g1.x, wx, g1.y * wy);
         const float ea = (__builtin_fabsf(g0.z) * ewx + __builtin_fabsf(g0.w) * ewy) * (1.0f + 4.0f * u) +
@@ -208,7 +212,7 @@ __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, cons
                     const float4 g0 = gp[0], g1 = gp[1];
                     float thi;
                     const float tlo = tri_bounds(j == 0u ? A0 : A1, g0, g1, tpar, thi);
-                    if (tlo <= best_up) {
+                    if (tlo <= best_up && tlo < __builtin_inff()) {                 // (+inf: certainly no hit -- also while best_up is still +inf)
                         best_up = fminf(best_up, thi);
                         if (qcnt < (uint32_t)kMeshQueue) {
                             lds_q[(size_t)qcnt * kBvhThreads + tid] = (first + k + j) | kQueueTri;
