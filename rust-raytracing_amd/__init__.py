@@ -377,7 +377,7 @@ class SceneHandle:
 
 HOST_SCENE_STATS = ("spheres", "triangles", "tri_filter_records", "tri_in_tree", "wide_nodes", "depth", "binary_nodes", "flags",
                     "sphere_leaf_entries", "tri_leaf_entries", "largest_leaf", "flat_nodes", "stack_bound", "tri_xy_footprints",
-                    "tri_other_footprints")
+                    "tri_other_footprints", "quantised_nodes")
 
 
 def debug_host_scene(scene):

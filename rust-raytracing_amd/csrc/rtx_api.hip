@@ -186,6 +186,7 @@ struct PackedScene {
     std::vector<uint8_t> tri_rec_free_axis;          // per tree record (leaf order): the axis its footprint is unbounded along
     BvhBuild bvh;
     Bvh4Build bvh4;
+    std::vector<BvhQNode> qnodes;                    // the 64-byte form of bvh4's nodes, when the tree allows it
 };
 
 int32_t pack_scene(const RtxScene *scene, PackedScene &p)
@@ -370,6 +371,8 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     p.sv.bvh_inv_max = (float)std::fmin(1.0e30, 1.0e37 / std::fmax(bvh.origin_limit, 1.0));     // |o * inv|, |b * inv| stay finite in f32
     p.sv.bvh_flags = (bvh.has_spheres ? 1u : 0u) | (bvh.has_tris ? 2u : 0u) |
                      (bvh.has_tris && !bvh.has_spheres && tree_recs[1].empty() && tree_recs[0].empty() ? 4u : 0u);
+    if ((p.sv.bvh_flags & 4u) && build_qnodes(bvh4, p.qnodes)) p.sv.bvh_flags |= 8u;
+    else p.qnodes.clear();
     if (std::getenv("RTX_HIP_DEBUG"))
         std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree: %zu xy / %zu xz / %zu yz footprints, %zu tested per segment), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
                      spheres.size(), tris.size(), n_in_tree, tree_recs[2].size(), tree_recs[1].size(), tree_recs[0].size(),
@@ -413,6 +416,7 @@ int32_t upload_packed(RtxSceneHandle_ *h, const PackedScene &p)
 
     int32_t rc = RTX_OK;
     if (!rc) rc = upload_vec(h, p.bvh4.nodes, &h->sv.bvh_nodes);
+    if (!rc) rc = upload_vec(h, p.qnodes, &h->sv.bvh_qnodes);
     if (!rc) rc = upload_vec(h, p.bvh.prims, &h->sv.bvh_prims);
     if (!rc) rc = upload_vec(h, p.leaf32, &h->sv.bvh_leaf_f32);
     if (!rc) rc = upload_vec(h, p.leaf_cr, &h->sv.bvh_leaf_cr);
@@ -1076,6 +1080,27 @@ int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
                 }
             }
         }
+    }
+    if (p.sv.bvh_flags & 8u) {                     // the 64-byte form: every decoded child rectangle contains the 128-byte node's
+        if (p.qnodes.size() != n_nodes) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised node count differs");
+        for (size_t k = 0; k < n_nodes; ++k) {
+            const Bvh4Node &w = p.bvh4.nodes[k];
+            const BvhQNode &q = p.qnodes[k];
+            const float lk[4] = { w.b[0].x, w.b[0].y, w.b[0].z, w.b[0].w }, ct[4] = { w.b[1].x, w.b[1].y, w.b[1].z, w.b[1].w };
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t count = bits(ct[c]), type = q.link[c] >> 30;
+                if ((count == 0xFFFFFFFFu) != (type == 3u)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised node: empty slot differs");
+                if (type == 3u) continue;
+                if ((q.link[c] & 0x3FFFFFFFu) != (bits(lk[c]) & ~kBvhFlatNode) || (type == 0u) != (count == 0u) ||
+                    (type != 0u && type != (count & 0xFFFFu)))
+                    return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised node: link / count differs");
+                const double lx = (double)q.ox + (double)(q.qx[c] & 0xFFFFu) * q.sx, hx = (double)q.ox + (double)(q.qx[c] >> 16) * q.sx;
+                const double ly = (double)q.oy + (double)(q.qy[c] & 0xFFFFu) * q.sy, hy = (double)q.oy + (double)(q.qy[c] >> 16) * q.sy;
+                if (!(lx <= (double)w.a[c].x && ly <= (double)w.a[c].y && hx >= (double)w.a[c].z && hy >= (double)w.a[c].w))
+                    return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised rectangle does not contain the child's");
+            }
+        }
+        stats[15] = p.qnodes.size();
     }
     if (depth != p.bvh4.depth) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: recorded depth differs");
     for (size_t k = 0; k < n_nodes; ++k) if (!node_seen[k]) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: unreachable node");

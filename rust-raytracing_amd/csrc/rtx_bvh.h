@@ -444,4 +444,65 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
     return out;
 }
 
+// ---- 64-byte footprint nodes ------------------------------------------------------------------------------------------
+// The walk of a mesh is bound by how many address-divergent 16-byte requests the L1 serves: a footprint
+// node costs 6.  When the tree holds nothing but (x, y) footprints and no leaf has more than 2 records, every wide node
+// also exists in a 4-request form: the four child rectangles as 16-bit offsets from the node's own rectangle,
+//     {ox, oy, sx, sy}   {lo.x | hi.x << 16} x 4   {lo.y | hi.y << 16} x 4   {type << 30 | index} x 4
+// child plane = ox + q * sx with sx a power of two (so q * sx is exact), lo rounded down, hi rounded up: the decoded
+// rectangle contains the f32 rectangle of the 128-byte node, which already carries the padding the f32 slab test needs;
+// type 0 = interior (index = wide node), 1 / 2 = triangle leaf with that many records (index = first record), 3 = empty.
+struct BvhQNode {
+    float ox, oy, sx, sy;
+    uint32_t qx[4], qy[4], link[4];
+};
+static_assert(sizeof(BvhQNode) == 64, "BvhQNode must be 64 bytes");
+
+inline bool build_qnodes(const Bvh4Build &b4, std::vector<BvhQNode> &out)
+{
+    out.clear();
+    out.reserve(b4.nodes.size());
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    for (const Bvh4Node &w : b4.nodes) {
+        const uint32_t lk[4] = { bits(w.b[0].x), bits(w.b[0].y), bits(w.b[0].z), bits(w.b[0].w) };
+        const uint32_t ct[4] = { bits(w.b[1].x), bits(w.b[1].y), bits(w.b[1].z), bits(w.b[1].w) };
+        double lo[2] = { INFINITY, INFINITY }, hi[2] = { -INFINITY, -INFINITY };
+        for (int c = 0; c < 4; ++c) {
+            if (ct[c] == 0xFFFFFFFFu) continue;
+            const float r[4] = { w.a[c].x, w.a[c].y, w.a[c].z, w.a[c].w };
+            for (int k = 0; k < 4; ++k) if (!std::isfinite(r[k])) return false;
+            lo[0] = std::min(lo[0], (double)r[0]); lo[1] = std::min(lo[1], (double)r[1]);
+            hi[0] = std::max(hi[0], (double)r[2]); hi[1] = std::max(hi[1], (double)r[3]);
+        }
+        BvhQNode q;
+        double o[2], sc[2];
+        for (int a = 0; a < 2; ++a) {
+            o[a] = std::isfinite(lo[a]) ? lo[a] : 0.0;
+            const double ext = std::isfinite(lo[a]) ? hi[a] - lo[a] : 0.0;
+            sc[a] = ext > 0.0 ? std::exp2(std::ceil(std::log2(ext / 65535.0))) : 1.0;
+            while (ext / sc[a] > 65535.0) sc[a] *= 2.0;                     // (log2 rounding)
+            if (!(sc[a] >= 1.1754944e-38 && sc[a] <= 1.0e30)) return false;   // must stay a normal f32
+        }
+        q.ox = (float)o[0]; q.oy = (float)o[1]; q.sx = (float)sc[0]; q.sy = (float)sc[1];
+        for (int c = 0; c < 4; ++c) {
+            if (ct[c] == 0xFFFFFFFFu) { q.qx[c] = 0x0000FFFFu; q.qy[c] = 0x0000FFFFu; q.link[c] = 3u << 30; continue; }
+            const double l0 = std::floor(((double)w.a[c].x - o[0]) / sc[0]), h0 = std::ceil(((double)w.a[c].z - o[0]) / sc[0]);
+            const double l1 = std::floor(((double)w.a[c].y - o[1]) / sc[1]), h1 = std::ceil(((double)w.a[c].w - o[1]) / sc[1]);
+            if (l0 < 0 || l1 < 0 || h0 > 65535 || h1 > 65535) return false;
+            q.qx[c] = (uint32_t)l0 | ((uint32_t)h0 << 16);
+            q.qy[c] = (uint32_t)l1 | ((uint32_t)h1 << 16);
+            uint32_t type;
+            if (ct[c] == 0u) type = 0u;
+            else if ((ct[c] & kBvhTriLeaf) && (ct[c] & 0xFFFFu) >= 1u && (ct[c] & 0xFFFFu) <= 2u) type = ct[c] & 0xFFFFu;
+            else return false;                                              // a sphere leaf or a bigger leaf: no 64-byte form
+            const uint32_t idx = lk[c] & ~kBvhFlatNode;
+            if (idx >= (1u << 30)) return false;
+            if (type == 0u && !(lk[c] & kBvhFlatNode)) return false;        // an interior child that is not a footprint node
+            q.link[c] = (type << 30) | idx;
+        }
+        out.push_back(q);
+    }
+    return true;
+}
+
 }  // namespace rtx

@@ -34,7 +34,7 @@ namespace rtx {
 #endif
 constexpr uint32_t kMeshWaves = RTX_MESH_WAVES;   // waves per SIMD (= workgroups per CU)
 constexpr int kMeshStack = (RTX_MESH_WAVES <= 4 ? 39 : 160 / RTX_MESH_WAVES) - 1 - 2 * kMeshQueue;   // LDS stack entries per lane: (entries + 1 sink row + 2 * kMeshQueue) KB per workgroup
-template <bool SPILL, bool PLAIN>
+template <bool SPILL, int PLAIN>
 __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel(const SceneView *__restrict__ svp,
                                                                                  const RowsView *__restrict__ rvp,
                                                                                  double *__restrict__ samples, Counters *__restrict__ ctr,
@@ -302,11 +302,18 @@ hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, con
     MeshArrays ma;
     ma.sphere_cr = sv.bvh_leaf_cr; ma.sphere_prims = sv.bvh_prims; ma.tri_f32 = sv.tri_f32; ma.tri_geo = sv.tri_geo;
     const uint32_t spill_entries = spill ? bvh_mesh_spill_entries(sv) : 0u;
-    const bool plain = (sv.bvh_flags & 4u) != 0u;       // nothing but (x, y)-footprint triangles in the tree
-    auto kernel = spill_entries != 0u ? (plain ? trace_bvh_mesh_kernel<true, true> : trace_bvh_mesh_kernel<true, false>)
-                                      : (plain ? trace_bvh_mesh_kernel<false, true> : trace_bvh_mesh_kernel<false, false>);
+    // 0: a joint tree; 1: nothing but (x, y)-footprint triangles; 2: ... with the 64-byte nodes (RTX_HIP_NO_QNODES=1: A/B runs)
+    static const bool no_q = std::getenv("RTX_HIP_NO_QNODES") != nullptr;
+    const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : ((sv.bvh_flags & 8u) != 0u && !no_q ? 2 : 1);
+    void (*kernel)(const SceneView *, const RowsView *, double *, Counters *, unsigned long long *, const float4 *, const LeafArrays,
+                   const MeshArrays, uint32_t *, uint32_t, uint32_t) = nullptr;
+    const bool deep = spill_entries != 0u;
+    if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2> : trace_bvh_mesh_kernel<false, 2>;
+    else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1> : trace_bvh_mesh_kernel<false, 1>;
+    else kernel = deep ? trace_bvh_mesh_kernel<true, 0> : trace_bvh_mesh_kernel<false, 0>;
+    const float4 *nodes = plain == 2 ? reinterpret_cast<const float4 *>(sv.bvh_qnodes) : reinterpret_cast<const float4 *>(sv.bvh_nodes);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
-                       reinterpret_cast<const float4 *>(sv.bvh_nodes), la, ma, spill, spill_entries, thresh);
+                       nodes, la, ma, spill, spill_entries, thresh);
     return hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ struct SceneView {
     double          sphere_cmax;               // max over spheres of |c - centre| + r
     // flat BVH over the sphere boxes and triangle footprints (rtx_bvh.h); null when the scene has none
     const Bvh4Node *bvh_nodes;                 // 4-wide nodes, 128 B each; node 0 is the root
+    const BvhQNode *bvh_qnodes;                // the same nodes in the 64-byte quantised form (bvh_flags bit 3), else null
     const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
     const float4   *bvh_leaf_f32;              // per sphere leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
     const float4   *bvh_leaf_cr;               // the same entries as {c - centre, |r|} (rounded up): the spheres kernel's record
@@ -50,7 +51,7 @@ struct SceneView {
     uint32_t        bvh_depth;
     uint32_t        pad2_;
     float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
-    uint32_t        bvh_flags;                 // bit 2: the tree holds nothing but (x, y)-footprint triangles (every node is a footprint node);
+    uint32_t        bvh_flags;                 // bit 3: bvh_qnodes is valid;  bit 2: the tree holds nothing but (x, y)-footprint triangles (every node is a footprint node);
                                                // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
     uint32_t        n_tri_tree;                // triangle filter records [0, n_tri_tree) are in leaf order (a triangle leaf's link
     float           bvh_inv_max;               // indexes them); [n_tri_tree, n_tri_filter) are outside the tree.  bvh_inv_max: rtx_traverse.h

@@ -93,17 +93,49 @@ struct MeshArrays {                          // kernel arguments (global address
 // PLAIN: the tree holds nothing but triangles with (x, y) footprints (C3, C5: no spheres, no faces solved in another
 // plane), so every node is a footprint node: 96 of its 128 bytes, a two-slab test, triangle leaves only -- the step then
 // needs neither the 3-D test nor the sphere bounds nor their registers.
-template <bool PLAIN> struct MeshNode { static constexpr int n = PLAIN ? 6 : 8; };
+// PLAIN == 2: ... and the tree has the 64-byte quantised nodes (rtx_bvh.h BvhQNode): 4 requests per node instead of 6.
+template <int PLAIN> struct MeshNode { static constexpr int n = PLAIN == 2 ? 4 : PLAIN == 1 ? 6 : 8; };
+
+// entry distance of a quantised child rectangle: plane = o + q * s, t = (plane - origin) * inv = q * (s * inv) + (o * inv + noi);
+// s is a power of two, so A = s * inv is exact, B is one fma rounding of a quantity of the size of a distance inside the
+// node (covered, like noi's rounding, by the boxes' absolute padding), t one more
+__device__ __forceinline__ float qrect_entry(uint32_t qx, uint32_t qy, float Ax, float Bx, float Ay, float By, float best_up)
+{
+    const float x0 = __builtin_fmaf((float)(qx & 0xFFFFu), Ax, Bx), x1 = __builtin_fmaf((float)(qx >> 16), Ax, Bx);
+    const float y0 = __builtin_fmaf((float)(qy & 0xFFFFu), Ay, By), y1 = __builtin_fmaf((float)(qy >> 16), Ay, By);
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), 0.0f);
+    const float tf = fminf(fmaxf(x0, x1), fmaxf(y0, y1));
+    const float tn_lo = tn * (1.0f - 4.76837158e-7f);
+    const float tf_hi = tf * (1.0f + 4.76837158e-7f);
+    return (tn_lo <= tf_hi && tn_lo <= best_up) ? tn_lo : __builtin_inff();
+}
+__device__ __forceinline__ float qnode_offset(float o, float inv, float noi) { return __builtin_fmaf(o, inv, noi); }
+__device__ __forceinline__ double qnode_offset(float o, double inv, double noi) { return __builtin_fma((double)o, inv, noi); }
+__device__ __forceinline__ float qrect_entry(uint32_t qx, uint32_t qy, double Ax, double Bx, double Ay, double By, float best_up)
+{
+    const double x0 = __builtin_fma((double)(qx & 0xFFFFu), Ax, Bx), x1 = __builtin_fma((double)(qx >> 16), Ax, Bx);
+    const double y0 = __builtin_fma((double)(qy & 0xFFFFu), Ay, By), y1 = __builtin_fma((double)(qy >> 16), Ay, By);
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), 0.0);
+    const double tf = fmin(fmax(x0, x1), fmax(y0, y1));
+    const double tn_lo = tn * (1.0 - 4.76837158e-7), tf_hi = tf * (1.0 + 4.76837158e-7);
+    return (tn_lo <= tf_hi && tn_lo <= (double)best_up) ? __double2float_rd(tn_lo) : __builtin_inff();
+}
 
 // The 128 bytes of wide node `idx` (a footprint node uses the first 96).
-template <bool PLAIN>
+template <int PLAIN>
 __device__ __forceinline__ void mesh_load_node(const float4 *__restrict__ nodes, uint32_t idx, float4 (&nd)[MeshNode<PLAIN>::n])
 {
-    const float4 *np = nodes + 8 * (size_t)(idx & ~kBvhFlatNode);
+    if constexpr (PLAIN == 2) {                   // `nodes` = the BvhQNode array
+        const float4 *np = nodes + 4 * (size_t)(idx & ~kBvhFlatNode);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) nd[c] = np[c];
-    if constexpr (!PLAIN) {
-        if (!(idx & kBvhFlatNode)) { nd[6] = np[6]; nd[7] = np[7]; }
+        for (int c = 0; c < 4; ++c) nd[c] = np[c];
+    } else {
+        const float4 *np = nodes + 8 * (size_t)(idx & ~kBvhFlatNode);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) nd[c] = np[c];
+        if constexpr (!PLAIN) {
+            if (!(idx & kBvhFlatNode)) { nd[6] = np[6]; nd[7] = np[7]; }
+        }
     }
 }
 
@@ -114,7 +146,7 @@ __device__ __forceinline__ void mesh_load_node(const float4 *__restrict__ nodes,
 // Returns false when the lane has to wait for the exact tests of what its queue holds (the queue cannot take the next
 // leaf's records): `resume` then holds the leaf children still to be read and `resume_node` the node they belong to; the
 // caller flushes, reloads nd for resume_node and calls again -- that call reads only those children and moves on to `node`.
-template <bool SPILL, bool PLAIN, int STACK, class RAY>
+template <bool SPILL, int PLAIN, int STACK, class RAY>
 __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, const MeshArrays &ma, const RAY &q, const SphereRay &sr,
                                           const TriFilterParams &tpar, float4 (&nd)[MeshNode<PLAIN>::n], uint32_t &node, uint32_t &sp, uint32_t &qcnt,
                                           bool &overflow, float &best_up, uint32_t &resume, uint32_t &resume_node, uint32_t *lds_stack,
@@ -124,7 +156,15 @@ __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, cons
     const uint32_t cur = resume != 0u ? resume_node : node;
     if constexpr (!kMeshPipe) mesh_load_node<PLAIN>(nodes, cur, nd);
     uint32_t lnk[4], cnt[4];
-    if (PLAIN || (cur & kBvhFlatNode)) {
+    if constexpr (PLAIN == 2) {
+        const uint32_t w[4] = { __float_as_uint(nd[3].x), __float_as_uint(nd[3].y), __float_as_uint(nd[3].z), __float_as_uint(nd[3].w) };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t type = w[c] >> 30;
+            lnk[c] = w[c] & 0x3FFFFFFFu;
+            cnt[c] = type == 0u ? 0u : (type == 3u ? 0xFFFFFFFFu : (type | kBvhTriLeaf));
+        }
+    } else if (PLAIN || (cur & kBvhFlatNode)) {
         lnk[0] = __float_as_uint(nd[4].x); lnk[1] = __float_as_uint(nd[4].y); lnk[2] = __float_as_uint(nd[4].z); lnk[3] = __float_as_uint(nd[4].w);
         cnt[0] = __float_as_uint(nd[5].x); cnt[1] = __float_as_uint(nd[5].y); cnt[2] = __float_as_uint(nd[5].z); cnt[3] = __float_as_uint(nd[5].w);
     } else if constexpr (!PLAIN) {
@@ -134,7 +174,14 @@ __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, cons
     uint32_t leafmask = 0, next = node;
     if (resume == 0u) {
         float tc[4];
-        if (PLAIN || (cur & kBvhFlatNode)) {
+        if constexpr (PLAIN == 2) {
+            const auto Ax = nd[0].z * q.ix, Ay = nd[0].w * q.iy;                  // (float or double with RAY)
+            const uint32_t qx[4] = { __float_as_uint(nd[1].x), __float_as_uint(nd[1].y), __float_as_uint(nd[1].z), __float_as_uint(nd[1].w) };
+            const uint32_t qy[4] = { __float_as_uint(nd[2].x), __float_as_uint(nd[2].y), __float_as_uint(nd[2].z), __float_as_uint(nd[2].w) };
+            const auto Bxf = qnode_offset(nd[0].x, q.ix, q.nx), Byf = qnode_offset(nd[0].y, q.iy, q.ny);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tc[c] = qrect_entry(qx[c], qy[c], Ax, Bxf, Ay, Byf, best_up);
+        } else if (PLAIN || (cur & kBvhFlatNode)) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) tc[c] = rect_entry32(nd[c], q, best_up);
         } else if constexpr (!PLAIN) {

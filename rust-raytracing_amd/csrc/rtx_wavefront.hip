@@ -24,6 +24,7 @@
 #include "rtx_mesh_step.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rtx {
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const SceneView *__res
 }
 
 // ---- the walk ------------------------------------------------------------------------------------------------------------
-template <bool SPILL>
+template <bool SPILL, int PLAIN>
 __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(const SceneView *__restrict__ svp, const WfState st,
                                                                               uint32_t level, Counters *__restrict__ ctr,
                                                                               const float4 *__restrict__ nodes, const MeshArrays ma,
@@ -179,8 +180,8 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
             continue;
         }
         if (busy) {
-            float4 nd[MeshNode<true>::n];
-            if (!mesh_step<SPILL, true, kWfStack>(nodes, ma, q, sr, tp, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq,
+            float4 nd[MeshNode<PLAIN>::n];
+            if (!mesh_step<SPILL, PLAIN, kWfStack>(nodes, ma, q, sr, tp, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq,
                                                   tid, spill, spill_entries, spill_stride, glane, nbox, nleaf)) {
                 overflow = true;                   // the queue cannot take the next leaf: the shade kernel walks this ray itself
                 node = kNone;
@@ -439,6 +440,8 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const uint32_t spill_entries = spill ? wavefront_spill_entries(sv) : 0u;
     const bool deep = spill_entries != 0u;
     const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
+    const float4 *qnodes = reinterpret_cast<const float4 *>(sv.bvh_qnodes);
+    const bool qn = (sv.bvh_flags & 8u) != 0u && !std::getenv("RTX_HIP_NO_QNODES");
     const uint32_t trace_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfTraceWaves);
     // (grid-stride; 4 workgroups per CU are resident, and the fallback walk's HBM stack column is indexed by the resident lane)
     const uint32_t shade_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * 4u);
@@ -458,8 +461,13 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
             WfState sk = st;
             sk.count = st.count + k; sk.work = st.work + k;
             sk.rec[0] = st.rec[k & 1u]; sk.rec[1] = st.rec[(k + 1u) & 1u];
-            if (deep) hipLaunchKernelGGL(wf_trace_kernel<true>, dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, nodes, ma, spill, spill_entries);
-            else hipLaunchKernelGGL(wf_trace_kernel<false>, dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, nodes, ma, spill, spill_entries);
+            if (qn) {
+                if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, qnodes, ma, spill, spill_entries);
+                else hipLaunchKernelGGL((wf_trace_kernel<false, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, qnodes, ma, spill, spill_entries);
+            } else {
+                if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, nodes, ma, spill, spill_entries);
+                else hipLaunchKernelGGL((wf_trace_kernel<false, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, nodes, ma, spill, spill_entries);
+            }
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (deep) hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level + k, samples, counters, nodes, la, spill, spill_entries);
             else hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level + k, samples, counters, nodes, la, spill, spill_entries);

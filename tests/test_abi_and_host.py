@@ -273,7 +273,7 @@ def test_bvh_invariants_on_the_benchmark_scenes(rtx):
     assert st["flags"] == 1 and st["sphere_leaf_entries"] == 10000 and st["largest_leaf"] == 1 and st["flat_nodes"] == 0
     assert st["depth"] <= 9 and st["stack_bound"] <= 30                          # C2 runs the LDS-stack-only kernel variant
     st = _host_scene(rtx, scenes.random_triangles(100000, 2))                    # C3
-    assert st["flags"] == 2 + 4 and st["tri_in_tree"] == st["tri_leaf_entries"] == st["tri_filter_records"]
+    assert st["flags"] == 2 + 4 + 8 and st["quantised_nodes"] == st["wide_nodes"] and st["tri_in_tree"] == st["tri_leaf_entries"] == st["tri_filter_records"]
     assert 45000 < st["tri_in_tree"] < 56000                                     # about half are culled for every direction
     assert st["flat_nodes"] == st["wide_nodes"] and st["largest_leaf"] == 2
     st = _host_scene(rtx, scenes.mixed_scene(60, 50, 2, seed=21))                # joint root: spheres + triangles

@@ -342,7 +342,7 @@ def test_mesh_kernel_paths(gpu, oracle):
 
     mesh = scenes.light_every(scenes.compact(scenes.random_triangles(4000, 6), k=0.05, x0=5.0))
     st = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), mesh))
-    assert st["flags"] == 2 + 4 and st["tri_other_footprints"] == 0 and st["flat_nodes"] == st["wide_nodes"]   # the PLAIN variant
+    assert st["flags"] == 2 + 4 + 8 and st["tri_other_footprints"] == 0 and st["flat_nodes"] == st["wide_nodes"]   # the PLAIN variant
     co = mesh.copy()
     co["geom"][100:114] = (3.0, -0.6, -0.5, 3.0, 0.7, -0.4, 3.1, 0.0, 0.8)        # 14 coincident triangles in front of the mesh
     co["emission_color"][100:114] = np.linspace(0.1, 0.9, 14)[:, None]
