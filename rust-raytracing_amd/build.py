@@ -10,8 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librtx_hip.so")
-SOURCES = ["rtx_kernels.hip", "rtx_bvh.hip", "rtx_bvh_spheres.hip", "rtx_bvh_regroup.hip", "rtx_bvh_mesh.hip", "rtx_wavefront.hip", "rtx_api.hip"]
-HEADERS = ["rtx_math.h", "rtx_scene.h", "rtx_bvh.h", "rtx_device.h", "rtx_traverse.h", "rtx_mesh_step.h", "rtx_launch.h"]
+SOURCES = ["rtx_kernels.hip", "rtx_bvh.hip", "rtx_bvh_spheres.hip", "rtx_bvh_spheres_pool.hip", "rtx_bvh_regroup.hip", "rtx_bvh_mesh.hip", "rtx_wavefront.hip", "rtx_wavefront_spheres.hip", "rtx_api.hip"]
+HEADERS = ["rtx_math.h", "rtx_scene.h", "rtx_bvh.h", "rtx_device.h", "rtx_traverse.h", "rtx_mesh_step.h", "rtx_wavefront.h", "rtx_launch.h"]
 # -ffp-contract=off: the exact path must round like the reference (Rust never fuses a*b+c);
 # the f32 filter asks for FMAs explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

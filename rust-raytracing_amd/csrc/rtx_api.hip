@@ -671,8 +671,11 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         }
     }
 
-    // the wavefront form exists for pure (x, y)-footprint triangle trees; any other scene takes the regrouping kernel
-    if (kernel == RTX_KERNEL_WAVEFRONT && (h->sv.bvh_flags & 4u) == 0u) kernel = RTX_KERNEL_BVH_REGROUP;
+    // the wavefront form exists for pure (x, y)-footprint triangle trees and for trees that hold spheres only; any other
+    // scene takes the regrouping kernel
+    const bool wf_mesh = (h->sv.bvh_flags & 4u) != 0u;
+    const bool wf_spheres = !wf_mesh && h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 3u) == 1u;
+    if (kernel == RTX_KERNEL_WAVEFRONT && !wf_mesh && !wf_spheres) kernel = RTX_KERNEL_BVH_REGROUP;
     // the BVH kernels' ray queue runs over 8x8 pixel tiles (a wave's 64 rays = one tile); a sample then has
     // tiles_x * tiles_y * 64 queue slots (the padding of partial tiles included), else npix
     const bool tiled = (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP || kernel == RTX_KERNEL_WAVEFRONT) && !std::getenv("RTX_HIP_NO_TILES");
@@ -740,8 +743,12 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     // the regrouping schedule on a tree with triangle leaves runs the mesh kernel (f32-only traversal step;
     // RTX_HIP_BVH_CLASSIC=1: trace_bvh_regroup_kernel)
     const bool mesh_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 2u) != 0u && !std::getenv("RTX_HIP_BVH_CLASSIC");
+    // the regrouping schedule on a tree without triangle leaves: the pool kernel (RTX_HIP_BVH_CLASSIC=1: round 1's)
+    const bool pool_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 3u) == 1u && h->sv.n_bvh_nodes != 0 &&
+                             !std::getenv("RTX_HIP_BVH_CLASSIC");
     if (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) {
-        const size_t need = spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus)
+        const size_t need = pool_kernel ? bvh_spheres_pool_bytes(h->sv, h->n_cus)
+                            : spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus)
                             : mesh_kernel ? bvh_mesh_spill_bytes(h->sv, h->n_cus) : bvh_spill_bytes(h->sv, h->n_cus);
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
     }
@@ -749,7 +756,8 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
     if (kernel == RTX_KERNEL_WAVEFRONT) {
-        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, wavefront_spill_bytes(h->sv, h->n_cus))) return rc;
+        const size_t need = wf_mesh ? wavefront_spill_bytes(h->sv, h->n_cus) : wavefront_spheres_spill_bytes(h->sv, h->n_cus);
+        if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, wavefront_state_bytes(batch * per_sample64, wavefront_levels(h->sv)))) return rc;
     }
 
@@ -788,11 +796,18 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
         } else if (kernel == RTX_KERNEL_WAVEFRONT) {
-            RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
-                                                 reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            if (wf_mesh)
+                RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
+                                                     reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            else
+                RTX_HIP_CHECK(launch_trace_wavefront_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
+                                                             reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            if (mesh_kernel)
+            if (pool_kernel)
+                RTX_HIP_CHECK(launch_trace_bvh_spheres_pool(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                                            h->state, h->n_cus, stream));
+            else if (mesh_kernel)
                 RTX_HIP_CHECK(launch_trace_bvh_mesh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                     reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
             else

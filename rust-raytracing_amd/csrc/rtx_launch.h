@@ -36,6 +36,14 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     hipStream_t stream);
 
+// RTX_KERNEL_BVH_REGROUP for trees that hold spheres only (rtx_bvh_spheres_pool.hip): every lane owns a pool of rays, the
+// f64 phase serves all of them, the walk runs the lane's pending segments one after the other with the waiting lanes
+// served together.  scratch: bvh_spheres_pool_bytes() bytes (the pools + the HBM stack columns).
+size_t bvh_spheres_pool_bytes(const SceneView &sv, int n_cus);
+hipError_t launch_trace_bvh_spheres_pool(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                         double *samples, Counters *counters, unsigned long long *work_counter, void *scratch,
+                                         int n_cus, hipStream_t stream);
+
 // The same traversal scheduled as a per-lane state machine (rtx_bvh_regroup.hip): lanes that finished their traversal
 // wait until enough of them can shade together instead of the whole wave waiting for its longest traversal.
 hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
@@ -59,6 +67,13 @@ uint32_t wavefront_levels(const SceneView &sv);
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                   double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream);
+
+// RTX_KERNEL_WAVEFRONT for trees that hold spheres only (rtx_wavefront_spheres.hip): walk / shade kernels per bounce level,
+// the walk's lanes refilled from the level's queue.  state_mem: wavefront_state_bytes(); spill: wavefront_spheres_spill_bytes().
+size_t wavefront_spheres_spill_bytes(const SceneView &sv, int n_cus);
+hipError_t launch_trace_wavefront_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                          double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus,
+                                          hipStream_t stream);
 
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in sample order).
 // samples: rv.n_rays 32-byte records in ray-queue order (store_sample, rtx_device.h); per_sample = queue slots

@@ -99,19 +99,22 @@ template <int PLAIN> struct MeshNode { static constexpr int n = PLAIN == 2 ? 4 :
 // entry distance of a quantised child rectangle: plane = o + q * s, t = (plane - origin) * inv = q * (s * inv) + (o * inv + noi);
 // s is a power of two, so A = s * inv is exact, B is one fma rounding of a quantity of the size of a distance inside the
 // node (covered, like noi's rounding, by the boxes' absolute padding), t one more
-__device__ __forceinline__ float qrect_entry(uint32_t qx, uint32_t qy, float Ax, float Bx, float Ay, float By, float best_up)
+// (e: Ray32S's slack, 0 for Ray32 -- it covers the rounding of noi inside B for origins the padding does not; the node's own
+// o * inv term is of the size of a distance inside the scene and stays covered by the padding)
+__device__ __forceinline__ float qrect_entry(uint32_t qx, uint32_t qy, float Ax, float Bx, float Ay, float By, float best_up, float e)
 {
     const float x0 = __builtin_fmaf((float)(qx & 0xFFFFu), Ax, Bx), x1 = __builtin_fmaf((float)(qx >> 16), Ax, Bx);
     const float y0 = __builtin_fmaf((float)(qy & 0xFFFFu), Ay, By), y1 = __builtin_fmaf((float)(qy >> 16), Ay, By);
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), 0.0f);
     const float tf = fminf(fmaxf(x0, x1), fmaxf(y0, y1));
-    const float tn_lo = tn * (1.0f - 4.76837158e-7f);
-    const float tf_hi = tf * (1.0f + 4.76837158e-7f);
+    const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);
+    const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);
     return (tn_lo <= tf_hi && tn_lo <= best_up) ? tn_lo : __builtin_inff();
 }
+__device__ __forceinline__ double ray_slack(const Ray64 &) { return 0.0; }
 __device__ __forceinline__ float qnode_offset(float o, float inv, float noi) { return __builtin_fmaf(o, inv, noi); }
 __device__ __forceinline__ double qnode_offset(float o, double inv, double noi) { return __builtin_fma((double)o, inv, noi); }
-__device__ __forceinline__ float qrect_entry(uint32_t qx, uint32_t qy, double Ax, double Bx, double Ay, double By, float best_up)
+__device__ __forceinline__ float qrect_entry(uint32_t qx, uint32_t qy, double Ax, double Bx, double Ay, double By, float best_up, double)
 {
     const double x0 = __builtin_fma((double)(qx & 0xFFFFu), Ax, Bx), x1 = __builtin_fma((double)(qx >> 16), Ax, Bx);
     const double y0 = __builtin_fma((double)(qy & 0xFFFFu), Ay, By), y1 = __builtin_fma((double)(qy >> 16), Ay, By);
@@ -180,7 +183,7 @@ __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, cons
             const uint32_t qy[4] = { __float_as_uint(nd[2].x), __float_as_uint(nd[2].y), __float_as_uint(nd[2].z), __float_as_uint(nd[2].w) };
             const auto Bxf = qnode_offset(nd[0].x, q.ix, q.nx), Byf = qnode_offset(nd[0].y, q.iy, q.ny);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) tc[c] = qrect_entry(qx[c], qy[c], Ax, Bxf, Ay, Byf, best_up);
+            for (int c = 0; c < 4; ++c) tc[c] = qrect_entry(qx[c], qy[c], Ax, Bxf, Ay, Byf, best_up, ray_slack(q));
         } else if (PLAIN || (cur & kBvhFlatNode)) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) tc[c] = rect_entry32(nd[c], q, best_up);

@@ -17,6 +17,13 @@ struct Ray32 { float ix, iy, iz, nx, ny, nz; };
 // the boxes' padding covers up to |o| <= 2^27 * origin_limit.  Without it such a ray would test every shape exactly --
 // 0.3 s for one segment over 500k triangles, while its wave and the launch wait.
 struct Ray64 { double ix, iy, iz, nx, ny, nz; };
+// Ray32 with an absolute slack on every slab distance, for the same far origins where no f64 is wanted (the wavefront
+// walk kernels): what the boxes' padding no longer covers is the rounding of noi = fl(-o * inv), at most 2^-24 |o * inv|
+// per axis, so the interval [tn, tf] is widened by e = 2^-23 max_axis |noi| on both sides -- conservative for any finite
+// origin, and e = 0 (the same bits as Ray32) for origins inside origin_limit.
+struct Ray32S { float ix, iy, iz, nx, ny, nz, e; };
+__device__ __forceinline__ float ray_slack(const Ray32 &) { return 0.0f; }
+__device__ __forceinline__ float ray_slack(const Ray32S &r) { return r.e; }
 
 // |1/d| is clamped to inv_max (SceneView::bvh_inv_max, <= 1e30 and small enough that o * inv stays finite): an
 // axis the ray is (almost) parallel to then gives two huge finite distances of the right signs instead of inf / NaN.
@@ -43,17 +50,26 @@ __device__ __forceinline__ void make_ray32(const V3 &pos, const V3 &dirn, double
 //   < 2^-22 on every t, for which the interval is widened by 2^-21 |t|.
 // A NaN can only come from 0 * huge (never: inv is finite) or from a z slab of +-inf bounds times a finite inv
 // (never NaN either), so plain min/max are safe; an unbounded z slab gives -inf/+inf and drops out.
-__device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, const Ray32 &r, float best_up)
+template <class R32>
+__device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, const R32 &r, float best_up)
 {
     const float x0 = __builtin_fmaf(lo.x, r.ix, r.nx), x1 = __builtin_fmaf(hi.x, r.ix, r.nx);
     const float y0 = __builtin_fmaf(lo.y, r.iy, r.ny), y1 = __builtin_fmaf(hi.y, r.iy, r.ny);
     const float z0 = __builtin_fmaf(lo.z, r.iz, r.nz), z1 = __builtin_fmaf(hi.z, r.iz, r.nz);
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    const float tn_lo = tn * (1.0f - 4.76837158e-7f);                   // tn >= 0: (1 - 2^-21) tn is a lower bound
-    const float tf_hi = tf * (1.0f + 4.76837158e-7f);                   // an upper bound when tf >= 0 (else a miss anyway)
+    const float e = ray_slack(r);
+    const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);   // tn >= 0: (1 - 2^-21) tn is a lower bound
+    const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);    // an upper bound when tf >= 0 (else a miss anyway)
     const bool hit = (tn_lo <= tf_hi) && (tn_lo <= best_up);
     return hit ? tn_lo : __builtin_inff();      // the widened (conservative) entry distance
+}
+
+// origin_limit < |o|_inf: the slack of Ray32S (rounded up); 0 inside the range the padding covers
+__device__ __forceinline__ float ray32_slack(float nx, float ny, float nz, bool in_range)
+{
+    const float m = fmaxf(fmaxf(__builtin_fabsf(nx), __builtin_fabsf(ny)), __builtin_fabsf(nz));
+    return in_range ? 0.0f : m * (1.1920929e-7f * (1.0f + 9.5367432e-7f));
 }
 
 __device__ __forceinline__ void make_ray64(const V3 &pos, const V3 &dirn, double inv_max, Ray64 &r)
@@ -80,14 +96,16 @@ __device__ __forceinline__ float box_entry32(const float4 lo, const float4 hi, c
 }
 
 // The same tests for a footprint node's child {lo.x, lo.y, hi.x, hi.y} (rtx_bvh.h): two slabs.
-__device__ __forceinline__ float rect_entry32(const float4 r4, const Ray32 &r, float best_up)
+template <class R32>
+__device__ __forceinline__ float rect_entry32(const float4 r4, const R32 &r, float best_up)
 {
     const float x0 = __builtin_fmaf(r4.x, r.ix, r.nx), x1 = __builtin_fmaf(r4.z, r.ix, r.nx);
     const float y0 = __builtin_fmaf(r4.y, r.iy, r.ny), y1 = __builtin_fmaf(r4.w, r.iy, r.ny);
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), 0.0f);
     const float tf = fminf(fmaxf(x0, x1), fmaxf(y0, y1));
-    const float tn_lo = tn * (1.0f - 4.76837158e-7f);
-    const float tf_hi = tf * (1.0f + 4.76837158e-7f);
+    const float e = ray_slack(r);
+    const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);
+    const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);
     const bool hit = (tn_lo <= tf_hi) && (tn_lo <= best_up);
     return hit ? tn_lo : __builtin_inff();
 }
@@ -320,6 +338,117 @@ __device__ __forceinline__ void sphere_ray_from(const SceneView &sv, V3 pos, V3 
     f.K = __double2float_ru(24.0 * u * M);
 }
 
+// One visit of the walk: open `node`, test its four boxes, bound the spheres of the leaves the ray enters, push the
+// interior children still in reach (nearest on top) and pop the next node (kNone: the walk is complete).
+template <int STACK, bool SPILL, class RAY>
+__device__ __forceinline__ void sphere_step(const float4 *__restrict__ nodes, const float4 *__restrict__ leaf_f32,
+                                            const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
+                                            uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                            uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                            size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
+                                            uint32_t &nbox, uint32_t &nleaf)
+{
+    const float4 *np = nodes + 8 * (size_t)node;
+    float4 ca[4], cb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
+    float tc[4];
+    uint32_t lnk[4], cnt[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        tc[c] = box_entry32(ca[c], cb[c], q, best_up);
+        lnk[c] = __float_as_uint(ca[c].w);
+        cnt[c] = __float_as_uint(cb[c].w);
+    }
+    nbox += 4;
+    uint32_t leafmask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (tc[c] < __builtin_inff() && cnt[c] - 1u < 0xFFFFu) leafmask |= 1u << c;              // a sphere leaf the ray enters
+    while (leafmask != 0u) {
+        const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
+        leafmask &= leafmask - 1u;
+        const uint32_t first = c == 0 ? lnk[0] : (c == 1 ? lnk[1] : (c == 2 ? lnk[2] : lnk[3]));
+        const uint32_t n = (c == 0 ? cnt[0] : (c == 1 ? cnt[1] : (c == 2 ? cnt[2] : cnt[3]))) & 0xFFFFu;
+        for (uint32_t k = 0; k < n; ++k) {
+            const float4 rec = leaf_f32[first + k];                              // {c - centre, r}
+            const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+            const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+            const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
+            const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+            const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+            const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+            const float Dp = Dl + G;
+            if (Dp >= 0.0f) {                                                     // the exact test cannot be excluded
+                const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+                const float Dm = Dl - G;
+                // Delta > 0 for certain: t <= t_hi.  t_hi < 0 (the origin is inside the sphere or past it): the reference's
+                // near root is negative and closest_object drops it (scene.rs:249) -- not a candidate at all
+                const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+                if (tlo <= best_up && !(thi < 0.0f)) {                            // (else it cannot be the winner)
+                    if (tlo > sr.K) best_up = fminf(best_up, thi);                // certainly reported: bounds the winner's distance
+                    if (qcnt == (uint32_t)kSphQueue) {                            // drop the entries a later certain hit has overtaken
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int e = 0; e < kSphQueue; ++e) {
+                            const uint32_t ie = lds_q[(size_t)e * kBvhThreads + tid];
+                            const uint32_t te = lds_q[(size_t)(kSphQueue + e) * kBvhThreads + tid];
+                            if (__uint_as_float(te) <= best_up) {
+                                lds_q[(size_t)w * kBvhThreads + tid] = ie;
+                                lds_q[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                                w += 1;
+                            }
+                        }
+                        qcnt = w;
+                    }
+                    if (qcnt == (uint32_t)kSphQueue) overflow = true;             // (the segment then tests every sphere exactly)
+                    else {
+                        lds_q[(size_t)qcnt * kBvhThreads + tid] = leaf_prims[first + k];
+                        lds_q[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                        qcnt += 1;
+                    }
+                }
+            }
+        }
+        nleaf += n;
+    }
+    // interior children still in reach, nearest first (as bvh_step)
+    float key[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) key[c] = (cnt[c] == 0u && tc[c] <= best_up) ? tc[c] : __builtin_inff();
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                           (key[3] < __builtin_inff() ? 1u : 0u);
+    if (sp + 3u <= (uint32_t)STACK) {
+#pragma unroll
+        for (uint32_t i = 1; i <= 3; ++i) {
+            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;       // (row STACK = the sink)
+            lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
+        }
+        sp += npush;
+    } else {
+#define RTX_PUSH(v)                                                                                      \
+        {                                                                                            \
+            if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
+            else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                \
+                spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;         \
+            } else overflow = true;                                                                  \
+        }
+        if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+        if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+        if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
+    }
+    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
+        node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+    }
+}
+
 template <int STACK, bool SPILL, class RAY>
 __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ nodes, const float4 *__restrict__ leaf_f32,
                                                      const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
@@ -330,107 +459,9 @@ __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ 
 {
     uint32_t sp = 0;
     uint32_t node = root;
-    while (node != kNone) {
-        const float4 *np = nodes + 8 * (size_t)node;
-        float4 ca[4], cb[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { ca[c] = np[c]; cb[c] = np[4 + c]; }
-        float tc[4];
-        uint32_t lnk[4], cnt[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tc[c] = box_entry32(ca[c], cb[c], q, best_up);
-            lnk[c] = __float_as_uint(ca[c].w);
-            cnt[c] = __float_as_uint(cb[c].w);
-        }
-        nbox += 4;
-        uint32_t leafmask = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (tc[c] < __builtin_inff() && cnt[c] - 1u < 0xFFFFu) leafmask |= 1u << c;              // a sphere leaf the ray enters
-        while (leafmask != 0u) {
-            const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
-            leafmask &= leafmask - 1u;
-            const uint32_t first = c == 0 ? lnk[0] : (c == 1 ? lnk[1] : (c == 2 ? lnk[2] : lnk[3]));
-            const uint32_t n = (c == 0 ? cnt[0] : (c == 1 ? cnt[1] : (c == 2 ? cnt[2] : cnt[3]))) & 0xFFFFu;
-            for (uint32_t k = 0; k < n; ++k) {
-                const float4 rec = leaf_f32[first + k];                              // {c - centre, r}
-                const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
-                const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
-                const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
-                const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
-                const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
-                const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
-                const float Dp = Dl + G;
-                if (Dp >= 0.0f) {                                                     // the exact test cannot be excluded
-                    const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
-                    const float Dm = Dl - G;
-                    // Delta > 0 for certain: t <= t_hi.  t_hi < 0 (the origin is inside the sphere or past it): the reference's
-                    // near root is negative and closest_object drops it (scene.rs:249) -- not a candidate at all
-                    const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
-                    if (tlo <= best_up && !(thi < 0.0f)) {                            // (else it cannot be the winner)
-                        if (tlo > sr.K) best_up = fminf(best_up, thi);                // certainly reported: bounds the winner's distance
-                        if (qcnt == (uint32_t)kSphQueue) {                            // drop the entries a later certain hit has overtaken
-                            uint32_t w = 0;
-#pragma unroll
-                            for (int e = 0; e < kSphQueue; ++e) {
-                                const uint32_t ie = lds_q[(size_t)e * kBvhThreads + tid];
-                                const uint32_t te = lds_q[(size_t)(kSphQueue + e) * kBvhThreads + tid];
-                                if (__uint_as_float(te) <= best_up) {
-                                    lds_q[(size_t)w * kBvhThreads + tid] = ie;
-                                    lds_q[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
-                                    w += 1;
-                                }
-                            }
-                            qcnt = w;
-                        }
-                        if (qcnt == (uint32_t)kSphQueue) overflow = true;             // (the segment then tests every sphere exactly)
-                        else {
-                            lds_q[(size_t)qcnt * kBvhThreads + tid] = leaf_prims[first + k];
-                            lds_q[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
-                            qcnt += 1;
-                        }
-                    }
-                }
-            }
-            nleaf += n;
-        }
-        // interior children still in reach, nearest first (as bvh_step)
-        float key[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) key[c] = (cnt[c] == 0u && tc[c] <= best_up) ? tc[c] : __builtin_inff();
-#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
-        RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
-#undef RTX_CSWAP
-        const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
-                               (key[3] < __builtin_inff() ? 1u : 0u);
-        if (sp + 3u <= (uint32_t)STACK) {
-#pragma unroll
-            for (uint32_t i = 1; i <= 3; ++i) {
-                const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;       // (row STACK = the sink)
-                lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
-            }
-            sp += npush;
-        } else {
-#define RTX_PUSH(v)                                                                                      \
-            {                                                                                            \
-                if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
-                else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                \
-                    spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;         \
-                } else overflow = true;                                                                  \
-            }
-            if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
-            if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
-            if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
-#undef RTX_PUSH
-        }
-        node = key[0] < __builtin_inff() ? lnk[0] : kNone;
-        if (node == kNone && sp != 0u) {
-            sp -= 1;                        // its boxes are re-tested against the current bound when it is opened
-            node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
-                                                    : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
-        }
-    }
+    while (node != kNone)
+        sphere_step<STACK, SPILL>(nodes, leaf_f32, leaf_prims, q, sr, node, sp, lds_stack, lds_q, tid, spill, spill_entries,
+                                  spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
 }
 
 // A whole traversal of one lane's segment: steps until the stack is empty, the queued candidates' exact f64 tests

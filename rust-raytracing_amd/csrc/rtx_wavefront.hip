@@ -22,40 +22,22 @@
 // every shape when even the f64 slab test is out of range.
 #include "rtx_launch.h"
 #include "rtx_mesh_step.h"
+#include "rtx_wavefront.h"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace rtx {
 
-constexpr int kWfTraceWaves = 6;                                  // workgroups per CU of the walk kernel
+#ifndef RTX_WF_SERVICE
+#define RTX_WF_SERVICE 8
+#endif
+constexpr uint32_t kWfService = RTX_WF_SERVICE;                   // lanes of a wave that wait before they are served together
+#ifndef RTX_WF_TRACE_WAVES
+#define RTX_WF_TRACE_WAVES 4
+#endif
+constexpr int kWfTraceWaves = RTX_WF_TRACE_WAVES;                                  // workgroups per CU of the walk kernel
 constexpr int kWfStack = 160 / kWfTraceWaves - 1 - 2 * kMeshQueue;   // 13 LDS stack entries per lane, the HBM column behind them
-constexpr uint32_t kWfFallback = 0x80000000u;                     // cand.count flag: the shade kernel walks this ray itself
-
-struct WfRec {                        // 64 bytes: what the f32 walk needs of one segment
-    float px, py, pz;                 // origin - scene centre
-    float dx, dy, dz;                 // direction
-    float ix, iy, iz, nx, ny, nz;     // Ray32: inv = fl(1/d), noi = fl(-o * inv)
-    float best_up;                    // the self-hit's distance rounded up, or +inf; NaN: no f32 walk (see kWfFallback)
-    float A;                          // tri_filter_from_ray's slack 64uS
-    uint32_t ridx;                    // the ray (index in the launch's queue order)
-    uint32_t pad;
-};
-static_assert(sizeof(WfRec) == 64, "WfRec must be 64 bytes");
-
-struct WfCand { uint32_t count; uint32_t e[7]; };                 // 32 bytes per queue position
-static_assert(sizeof(WfCand) == 32, "WfCand must be 32 bytes");
-
-struct WfState {                      // structure-of-arrays over the launch's rays (capacity n), all on the device
-    double *pos[3], *dir[3], *res[3], *lig[3];
-    double *hit_t;                    // the pre-tested self-hit's distance, 0.0 = none
-    uint32_t *left;                   // the triangle the ray just left (index in tris[]), kNone = none
-    WfRec *rec[2];                    // [0]: the records of the level being processed, [1]: where the next level's go
-    WfCand *cand;
-    unsigned long long *count;        // count[0]: this level's queue length, count[1]: the next level's (being appended to)
-    unsigned long long *work;         // work[0]: the walk kernel's queue head for this level
-    uint64_t n;
-};
 
 __device__ __forceinline__ void wf_make_rec(const SceneView &sv, const V3 &pos, const V3 &dir, const V3 &dirn, float best_up,
                                             uint32_t ridx, WfRec &w)
@@ -68,24 +50,13 @@ __device__ __forceinline__ void wf_make_rec(const SceneView &sv, const V3 &pos, 
     w.dx = tp.dx; w.dy = tp.dy; w.dz = tp.dz;
     w.ix = q.ix; w.iy = q.iy; w.iz = q.iz; w.nx = q.nx; w.ny = q.ny; w.nz = q.nz;
     w.A = tp.A;
+    // an origin outside origin_limit (a bounce off one of the reference's far phantom hits) walks with Ray32S's slack; beyond
+    // 2^27 times that, or NaN: no walk (the shade kernel tests every shape)
     const float omax = fmaxf(fmaxf(__builtin_fabsf((float)pos.x), __builtin_fabsf((float)pos.y)), __builtin_fabsf((float)pos.z));
-    w.best_up = omax <= sv.bvh_origin_limit ? best_up : __builtin_nanf("");       // NaN origin -> no walk either
+    const bool in32 = omax <= sv.bvh_origin_limit;
+    w.slack = ray32_slack(q.nx, q.ny, q.nz, in32);
+    w.best_up = (in32 || omax <= sv.bvh_origin_limit * kBvhRange64) ? best_up : __builtin_nanf("");
     w.ridx = ridx;
-    w.pad = 0;
-}
-
-// wave-aggregated append: one atomic per wave, the lanes that append get consecutive slots
-__device__ __forceinline__ unsigned long long wf_append_slot(unsigned long long *counter, bool want)
-{
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull) return 0ull;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-    base = ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(base >> 32), leader) << 32) |
-           __builtin_amdgcn_readlane((uint32_t)base, leader);
-    return base + bvh_mbcnt(m);
 }
 
 // ---- level 0: render_pixel's prologue for every ray of the launch --------------------------------------------------------
@@ -101,6 +72,9 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const SceneView *__res
         if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, i, pl, smp);
         else ray_index_to_pixel(rv, i, pl, smp);
     }
+    // level 0's queue is the launch's ray queue itself (slot i = ray i, no atomics); the padding of partial tiles is marked dead
+    if (i == 0) st.count[0] = rv.n_rays;
+    if (i >= rv.n_rays) return;
     WfRec w;
     if (valid) {
         RayState r;
@@ -112,9 +86,11 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const SceneView *__res
         st.hit_t[i] = 0.0;
         st.left[i] = kNone;
         wf_make_rec(sv, r.pos, r.dir, vnorm(r.dir), __builtin_inff(), (uint32_t)i, w);
+    } else {
+        w.px = w.py = w.pz = w.dx = w.dy = w.dz = w.ix = w.iy = w.iz = w.nx = w.ny = w.nz = w.best_up = w.A = 0.f;
+        w.ridx = kNone; w.slack = 0.f;
     }
-    const unsigned long long slot = wf_append_slot(&st.count[0], valid);
-    if (valid) st.rec[0][slot] = w;
+    st.rec[0][i] = w;
 }
 
 // ---- the walk ------------------------------------------------------------------------------------------------------------
@@ -136,57 +112,30 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
     unsigned long long *const head = &st.work[0];
     (void)level;
 
-    bool busy = false, drained = false;
-    unsigned long long pos = 0;
-    Ray32 q;
+    const unsigned long long grab = wf_grab_size(n_queue);
+    WfChunk ch;
+    ch.next = ch.end = 0; ch.drained = false;
+    bool walking = false, have = false;           // have: the lane holds a segment (walking, or complete and not yet written)
+    uint32_t pos = 0, ridx = 0;
+    Ray32S q;
     SphereRay sr;                                 // (unused by the PLAIN step)
     TriFilterParams tp;
     float best_up = 0.f;
     uint32_t node = kNone, sp = 0, qcnt = 0, resume = 0, resume_node = 0, nbox = 0, nleaf = 0;
-    bool overflow = false;
+    bool overflow = false, extra = false;
     unsigned long long box_tests = 0, leaf_filters = 0;
     sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
-    q.ix = q.iy = q.iz = q.nx = q.ny = q.nz = 0.f;
+    q.ix = q.iy = q.iz = q.nx = q.ny = q.nz = q.e = 0.f;
     tri_filter_idle(tp);
 
     for (;;) {
-        // ---- idle lanes take the next rays of the queue: one atomic per refill, consecutive records -> coalesced loads
-        const unsigned long long idle = __ballot(!busy);
-        if (idle != 0ull && !drained && ((uint32_t)__popcll(idle) >= 8u || idle == ~0ull)) {
-            const unsigned long long slot = wf_append_slot(head, !busy);
-            if (__ballot(!busy && slot < n_queue) == 0ull) drained = true;       // the head ran past the queue: nothing left
-            if (!busy && slot < n_queue) {
-                const WfRec w = recs[slot];
-                pos = slot;
-                q.ix = w.ix; q.iy = w.iy; q.iz = w.iz; q.nx = w.nx; q.ny = w.ny; q.nz = w.nz;
-                tp.dx = w.dx; tp.dy = w.dy; tp.dz = w.dz; tp.npx = -w.px; tp.npy = -w.py; tp.npz = -w.pz; tp.A = w.A; tp.pad = 0.f;
-                best_up = w.best_up;
-                qcnt = 0; sp = 0; resume = 0; overflow = false;
-                busy = true;
-                if (best_up == best_up) node = sv.bvh_root;
-                else {                             // no f32 walk for this origin: the shade kernel takes it
-                    node = kNone;
-                    WfCand c;
-                    c.count = kWfFallback;
-#pragma unroll
-                    for (int e = 0; e < 7; ++e) c.e[e] = 0u;
-                    st.cand[pos] = c;
-                    busy = false;
-                }
-            }
-        }
-        if (__ballot(busy) == 0ull) {
-            if (drained) break;
-            continue;
-        }
-        if (busy) {
-            float4 nd[MeshNode<PLAIN>::n];
-            if (!mesh_step<SPILL, PLAIN, kWfStack>(nodes, ma, q, sr, tp, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq,
-                                                  tid, spill, spill_entries, spill_stride, glane, nbox, nleaf)) {
-                overflow = true;                   // the queue cannot take the next leaf: the shade kernel walks this ray itself
-                node = kNone;
-            }
-            if (node == kNone) {
+        // ---- lanes whose walk is complete wait until kWfService of the wave do; then they write their candidates and
+        //      take the next records of the wave's chunk of the queue (consecutive records -> coalesced loads)
+        const unsigned long long wmask = __ballot(walking);
+        const uint32_t n_fin = (uint32_t)__popcll(__ballot(!walking && have));
+        const bool serve = wmask == 0ull || (ch.drained ? n_fin >= kWfService : 64u - (uint32_t)__popcll(wmask) >= kWfService);
+        if (serve) {
+            if (!walking && have) {
                 WfCand c;
                 uint32_t k = 0;
 #pragma unroll
@@ -200,16 +149,211 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
                         k += 1;
                     }
                 }
-                c.count = overflow ? kWfFallback : k;
-#ifdef RTX_WF_DIAG
-                if (overflow) atomicAdd(&ctr[0].pad_, 1ull);
-#endif
+                c.count = ridx == kNone ? kWfDead : (overflow ? kWfFallback : (k | (extra ? kWfExtra : 0u)));
                 st.cand[pos] = c;
                 box_tests += nbox; leaf_filters += nleaf;
                 nbox = 0; nleaf = 0;
-                busy = false;
+                have = false;
+            }
+            if (!ch.drained) {
+                unsigned long long my;
+                if (wf_take(ch, head, grab, n_queue, !have, my)) {
+                    const WfRec w = recs[my];
+                    pos = (uint32_t)my;                          // (the host keeps a launch below 2^32 rays)
+                    ridx = w.ridx;
+                    q.ix = w.ix; q.iy = w.iy; q.iz = w.iz; q.nx = w.nx; q.ny = w.ny; q.nz = w.nz; q.e = w.slack;
+                    tp.dx = w.dx; tp.dy = w.dy; tp.dz = w.dz; tp.npx = -w.px; tp.npy = -w.py; tp.npz = -w.pz; tp.A = w.A; tp.pad = 0.f;
+                    best_up = w.best_up;
+                    qcnt = 0; sp = 0; resume = 0; overflow = false; extra = false;
+                    have = true;
+                    if (w.ridx == kNone) node = kNone;                               // a dead slot: passed on as such
+                    else if (best_up == best_up) { node = sv.bvh_root; walking = true; }
+                    else { node = kNone; overflow = true; }      // no f32 walk for this origin: the shade kernel takes it
+                }
+            }
+            if (__ballot(walking) == 0ull) {
+                if (ch.drained && __ballot(have) == 0ull) break;
+                continue;
             }
         }
+        if (walking) {
+            float4 nd[MeshNode<PLAIN>::n];
+            if (!mesh_step<SPILL, PLAIN, kWfStack>(nodes, ma, q, sr, tp, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq,
+                                                  tid, spill, spill_entries, spill_stride, glane, nbox, nleaf)) {
+                // the queue cannot take the next leaf: its live entries move to the level's overflow list and the step
+                // resumes with the leaf children it had not read (resume != 0); only a full list ends the walk here
+                if (wf_flush_to_extra(st, pos, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;
+                else { overflow = true; node = kNone; resume = 0; }
+            }
+            walking = node != kNone || resume != 0u;
+        }
+    }
+    unsigned long long filt = box_tests + leaf_filters;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        filt += __shfl_xor(filt, off, 64);
+        box_tests += __shfl_xor(box_tests, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);
+    }
+}
+
+// ---- the walk of level 0 as packets --------------------------------------------------------------------------------------
+// Level 0's queue is the launch's ray queue: 64 consecutive records are the primary rays of one 8x8 pixel tile of one
+// sample -- one origin (up to the aperture jitter), directions a few pixels apart.  They cross the same footprints, so
+// the wave walks the tree ONCE for all of them: one wave-uniform stack, the node and the leaf records read at a
+// wave-uniform address (one request instead of 64 address-divergent ones -- the gather rate is what bounds the per-lane
+// walk), every lane testing its own ray against them with its own bound.  A child is opened when any
+// lane's ray enters it; the order is the first entering lane's.  What a lane collects is what its own walk would have
+// collected for SOME visiting order -- every candidate that can still be the winner (t_lo <= its best_up) -- and the
+// exact tests decide as always.  Pure (x, y)-footprint trees; the 96-byte footprint nodes (at a uniform address the two
+// extra requests are free and the rectangles need no decoding).
+constexpr int kPkStack = 128;                                      // wave-uniform stack entries (the host checks 3 * depth + 2 against it)
+constexpr int kPkWaves = 6;                                        // workgroups per CU
+
+// wave-uniform reads through the scalar cache: the constant address space makes the compiler select s_load for them
+typedef float PkF4 __attribute__((ext_vector_type(4)));
+struct PkConst4 {
+    const __attribute__((address_space(4))) PkF4 *p;
+    __device__ __forceinline__ PkConst4 operator+(size_t i) const { return PkConst4{p + i}; }
+    __device__ __forceinline__ float4 operator[](size_t i) const { const PkF4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+};
+__device__ __forceinline__ PkConst4 pk_const(const float4 *p) { return PkConst4{(const __attribute__((address_space(4))) PkF4 *)(uintptr_t)p}; }
+__device__ __forceinline__ uint32_t pk_bits(float f) { return __builtin_amdgcn_readfirstlane(__float_as_uint(f)); }
+
+__global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(const WfState st, Counters *__restrict__ ctr,
+                                                                                const float4 *__restrict__ nodes, const MeshArrays ma,
+                                                                                uint32_t root)
+{
+    __shared__ uint32_t pk_stack[kBvhThreads >> 6][kPkStack];
+    __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];
+    uint32_t *const lq = &lds_q[0][0];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t *const stk = &pk_stack[tid >> 6][0];
+    const unsigned long long n_queue = st.count[0];
+    const unsigned long long n_tiles = (n_queue + 63ull) >> 6;
+    const WfRec *__restrict__ recs = st.rec[0];
+    unsigned long long *const head = &st.work[0];                  // counts tiles here
+    unsigned long long grab = n_tiles / ((unsigned long long)gridDim.x * (kBvhThreads >> 6) * 8ull);
+    grab = grab > 8ull ? 8ull : (grab < 1ull ? 1ull : grab);
+    unsigned long long t_next = 0, t_end = 0;
+    unsigned long long box_tests = 0, leaf_filters = 0;
+    const PkConst4 cnodes = pk_const(nodes), ctri = pk_const(ma.tri_f32), cgeo = pk_const(ma.tri_geo);
+
+    for (;;) {
+        if (t_next >= t_end) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(head, grab);
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                   __builtin_amdgcn_readfirstlane((uint32_t)base);
+            if (base >= n_tiles) break;
+            t_next = base;
+            t_end = base + grab < n_tiles ? base + grab : n_tiles;
+        }
+        const unsigned long long p = (t_next << 6) + lane;
+        t_next += 1;
+        WfRec w;
+        w.ridx = kNone; w.best_up = 0.f;
+        w.px = w.py = w.pz = w.dx = w.dy = w.dz = w.ix = w.iy = w.iz = w.nx = w.ny = w.nz = w.A = w.slack = 0.f;
+        if (p < n_queue) w = recs[p];
+        const bool valid = w.ridx != kNone;
+        const bool walk = valid && w.best_up == w.best_up;         // (NaN: no f32 walk for this origin)
+        bool overflow = valid && !walk, extra = false;
+        Ray32S q;
+        TriFilterParams tp;
+        q.ix = w.ix; q.iy = w.iy; q.iz = w.iz; q.nx = w.nx; q.ny = w.ny; q.nz = w.nz; q.e = w.slack;
+        tp.dx = w.dx; tp.dy = w.dy; tp.dz = w.dz; tp.npx = -w.px; tp.npy = -w.py; tp.npz = -w.pz; tp.A = w.A; tp.pad = 0.f;
+        float best_up = walk ? w.best_up : -__builtin_inff();       // -inf: this lane enters nothing
+        uint32_t qcnt = 0, nbox = 0, nleaf = 0;
+        uint32_t sp = 0;
+        uint32_t node = __ballot(walk) != 0ull ? (root & ~kBvhFlatNode) : kNone;
+
+        while (node != kNone) {
+            // the footprint node's 96 bytes at a wave-uniform address: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
+            const PkConst4 np = cnodes + 8 * (size_t)node;
+            const float4 r0 = np[0], r1 = np[1], r2 = np[2], r3 = np[3], l4 = np[4], c4 = np[5];
+            const uint32_t lnk[4] = { pk_bits(l4.x), pk_bits(l4.y), pk_bits(l4.z), pk_bits(l4.w) };
+            const uint32_t cnt[4] = { pk_bits(c4.x), pk_bits(c4.y), pk_bits(c4.z), pk_bits(c4.w) };
+            float tc[4];
+            tc[0] = rect_entry32(r0, q, best_up); tc[1] = rect_entry32(r1, q, best_up);
+            tc[2] = rect_entry32(r2, q, best_up); tc[3] = rect_entry32(r3, q, best_up);
+            if (best_up >= 0.0f) nbox += 4;
+            uint32_t key[4], kl[4];                                // keys: the bits of a non-negative float order like the float
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool in = tc[c] < __builtin_inff();
+                const unsigned long long hm = __ballot(in);
+                key[c] = 0x7F800000u;
+                kl[c] = lnk[c] & ~kBvhFlatNode;
+                if (hm == 0ull || cnt[c] == 0xFFFFFFFFu) continue;
+                if (cnt[c] == 0u) {                                // interior: opened for the wave, ordered by its first entering lane
+                    const int k = (int)__builtin_amdgcn_readlane(__float_as_uint(tc[c]), (int)(__ffsll((long long)hm) - 1));
+                    key[c] = (uint32_t)(k < 0 ? 0 : k);            // (a slack can make the bound negative)
+                    continue;
+                }
+                // a triangle leaf (uniform addresses): the lanes that enter it filter and bound its records
+                const uint32_t first = lnk[c], n = cnt[c] & 0xFFFFu;
+                if (in) nleaf += n;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const PkConst4 rp = ctri + 2 * (size_t)(first + j);
+                    const float4 A = rp[0], B = rp[1];
+                    const bool pass = in && (int)tri_filter_sign(A, B, tp) >= 0;
+                    if (__ballot(pass) == 0ull) continue;
+                    const PkConst4 gp = cgeo + 2 * (size_t)(first + j);
+                    const float4 g0 = gp[0], g1 = gp[1];
+                    if (pass) {
+                        float thi;
+                        const float tlo = tri_bounds(A, g0, g1, tp, thi);
+                        if (tlo <= best_up && tlo < __builtin_inff()) {
+                            best_up = fminf(best_up, thi);
+                            if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {       // more live candidates than the queue holds:
+                                if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;   // to the overflow list
+                                else { overflow = true; best_up = -__builtin_inff(); }     // (full: the shade kernel walks this ray)
+                            }
+                            if (!overflow) {
+                                lq[(size_t)qcnt * kBvhThreads + tid] = (first + j) | kQueueTri;
+                                lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                                qcnt += 1;
+                            }
+                        }
+                    }
+                }
+            }
+            // interior children any lane entered, nearest first (wave-uniform integer keys: scalar code); the farther ones go
+            // to the wave's stack
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { uint32_t tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = kl[i]; kl[i] = kl[j]; kl[j] = tl; } }
+            RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+            if (key[3] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[3]; sp += 1; }
+            if (key[2] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[2]; sp += 1; }
+            if (key[1] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[1]; sp += 1; }
+            node = key[0] < 0x7F800000u ? kl[0] : kNone;
+            if (node == kNone && sp != 0u) {
+                sp -= 1;
+                node = __builtin_amdgcn_readfirstlane(stk[sp]);
+            }
+        }
+        if (p < n_queue) {
+            WfCand c;
+            uint32_t k = 0;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) c.e[e] = 0u;
+#pragma unroll
+            for (int e = 0; e < kMeshQueue; ++e) {
+                if ((uint32_t)e < qcnt && __uint_as_float(lq[(size_t)(kMeshQueue + e) * kBvhThreads + tid]) <= best_up) {
+                    const uint32_t v = lq[(size_t)e * kBvhThreads + tid];
+                    c.e[0] = k == 0u ? v : c.e[0]; c.e[1] = k == 1u ? v : c.e[1]; c.e[2] = k == 2u ? v : c.e[2];
+                    c.e[3] = k == 3u ? v : c.e[3]; c.e[4] = k == 4u ? v : c.e[4]; c.e[5] = k == 5u ? v : c.e[5];
+                    k += 1;
+                }
+            }
+            c.count = !valid ? kWfDead : (overflow ? kWfFallback : (k | (extra ? kWfExtra : 0u)));
+            st.cand[p] = c;
+        }
+        box_tests += nbox; leaf_filters += nleaf;
     }
     unsigned long long filt = box_tests + leaf_filters;
 #pragma unroll
@@ -236,6 +380,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
     const RowsView &rv = *rvp;
     __shared__ uint32_t lds_stack[kBvh4StackEntries + 1][kBvhThreads];       // the fallback walk's (round 1's bvh_traverse)
     __shared__ uint32_t lds_q[kBvhQueue][kBvhThreads];
+    __shared__ uint32_t lds_append[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
@@ -245,14 +390,19 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
     unsigned long long segs = 0, exact = 0, box_tests = 0, leaf_filters = 0;
 
     // grid-stride over the level's queue (the grid is sized for the launch's ray count; deep levels are short)
-    for (unsigned long long p = (unsigned long long)blockIdx.x * kBvhThreads + tid; __ballot(p < n_queue) != 0ull;
-         p += (unsigned long long)gridDim.x * kBvhThreads) {
-        const bool have = p < n_queue;
+    // (block-uniform trip count: the append is one atomic per workgroup iteration)
+    uint32_t it = 0;
+    for (unsigned long long p0 = (unsigned long long)blockIdx.x * kBvhThreads; p0 < n_queue;
+         p0 += (unsigned long long)gridDim.x * kBvhThreads, ++it) {
+        const unsigned long long p = p0 + tid;
+        WfCand c;
+        c.count = kWfDead;
+        if (p < n_queue) c = st.cand[p];
+        const bool have = (c.count & kWfDead) == 0u;
         bool next = false;
         WfRec w;
         if (have) {
             const uint32_t ridx = recs[p].ridx;
-            const float rec_best = recs[p].best_up;
             RayState r;
             r.pos = mk(st.pos[0][ridx], st.pos[1][ridx], st.pos[2][ridx]);
             r.dir = mk(st.dir[0][ridx], st.dir[1][ridx], st.dir[2][ridx]);
@@ -263,13 +413,15 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
             const uint32_t left = st.left[ridx];
             const double ht = st.hit_t[ridx];
             if (ht != 0.0) { h.t = ht; h.id = la.tris[left].id; h.kind = 2; h.local = left; }     // the pre-tested self-hit
-            const WfCand c = st.cand[p];
             bool covered = true;
             if (c.count & kWfFallback) {
+#ifdef RTX_WF_DIAG
+                atomicAdd(&ctr[0].pad_, 1ull + ((unsigned long long)(level == 0u) << 32));
+#endif
                 covered = false;
                 const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
                                          __builtin_fabsf((float)r.pos.z));
-                const bool in32 = rec_best == rec_best, in64 = omax <= sv.bvh_origin_limit * kBvhRange64;
+                const bool in32 = omax <= sv.bvh_origin_limit, in64 = !in32 && omax <= sv.bvh_origin_limit * kBvhRange64;
                 if (in32 || in64) {                // round 1's walk: exact tests interleaved, f32 or f64 slab test
                     FilterParams fpar;
                     TriFilterParams tpar;
@@ -291,7 +443,19 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
                     covered = !ovf;
                 }
             } else {
-                const uint32_t n = c.count < 7u ? c.count : 7u;
+                const uint32_t nc = c.count & 0xFFFFu;
+                const uint32_t n = nc < 7u ? nc : 7u;
+                if (c.count & kWfExtra) {          // this walk's queue ran full: the rest of its candidates are in the level's overflow list
+                    const unsigned long long nx = st.xcount[0] < (unsigned long long)kWfExtraCap ? st.xcount[0] : (unsigned long long)kWfExtraCap;
+                    for (unsigned long long i = 0; i < nx; ++i) {
+                        const uint2 x = st.extra[i];
+                        if (x.x != (uint32_t)p) continue;
+                        const uint32_t tk = la.tri_fidx[x.y & ~kQueueTri];
+                        double t;
+                        if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                        exact += 1;
+                    }
+                }
 #pragma unroll 1
                 for (uint32_t e = 0; e < n; ++e) {
                     const uint32_t idx = e == 0 ? c.e[0] : e == 1 ? c.e[1] : e == 2 ? c.e[2] : e == 3 ? c.e[3] : e == 4 ? c.e[4] : e == 5 ? c.e[5] : c.e[6];
@@ -357,7 +521,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
                 next = true;
             }
         }
-        const unsigned long long slot = wf_append_slot(&st.count[1], next);
+        const unsigned long long slot = wf_append_block(&st.count[1], next, lds_append, it);
         if (next) recs_out[slot] = w;
     }
 #pragma unroll
@@ -377,18 +541,14 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
-// The levels are enqueued without host round trips: every kernel reads its queue length from the device.  A level whose
-// queue is empty costs two near-empty launches, so paths that may run for more than kWfLevelsPerSync levels are checked
-// from the host every that many levels (max_bounces is 10 by default: one chunk).
-constexpr uint32_t kWfLevelsPerSync = 16;
-
 // Per ray of a launch: 12 f64 of state + the self-hit's distance + the triangle it left + two 64-byte records + 32 bytes of
-// candidates; per level two u64 counters.
+// candidates; per level three u64 counters; the overflow list.
 size_t wavefront_state_bytes(uint64_t n_rays, uint32_t levels)
 {
     (void)levels;
     return (size_t)n_rays * (13 * sizeof(double) + sizeof(uint32_t) + 2 * sizeof(WfRec) + sizeof(WfCand)) +
-           (size_t)(2 * kWfLevelsPerSync + 8) * sizeof(unsigned long long) + 32 * 256;      // (every array starts on a 256-byte boundary)
+           (size_t)(3 * kWfLevelsPerSync + 12) * sizeof(unsigned long long) + (size_t)kWfExtraCap * sizeof(uint2) +
+           40 * 256;                              // (every array starts on a 256-byte boundary)
 }
 
 uint32_t wavefront_levels(const SceneView &sv)
@@ -414,23 +574,8 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     if (rv.n_rays == 0) return hipSuccess;
     const uint32_t levels = wavefront_levels(sv);
     const uint64_t n = rv.n_rays;
-    // carve the state block
-    char *p = static_cast<char *>(state_mem);
     WfState st;
-    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-    for (int k = 0; k < 3; ++k) st.pos[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    for (int k = 0; k < 3; ++k) st.dir[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    for (int k = 0; k < 3; ++k) st.res[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    for (int k = 0; k < 3; ++k) st.lig[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    st.hit_t = reinterpret_cast<double *>(take(n * sizeof(double)));
-    st.left = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
-    st.rec[0] = reinterpret_cast<WfRec *>(take(n * sizeof(WfRec)));
-    st.rec[1] = reinterpret_cast<WfRec *>(take(n * sizeof(WfRec)));
-    st.cand = reinterpret_cast<WfCand *>(take(n * sizeof(WfCand)));
-    // counters for one chunk of levels at a time (re-zeroed per chunk; the carried-over queue length is copied to slot 0)
-    st.count = reinterpret_cast<unsigned long long *>(take((kWfLevelsPerSync + 2) * sizeof(unsigned long long)));
-    st.work = reinterpret_cast<unsigned long long *>(take((kWfLevelsPerSync + 2) * sizeof(unsigned long long)));
-    st.n = n;
+    wf_carve(state_mem, n, st);
 
     LeafArrays la;
     la.sphere_f32 = sv.bvh_leaf_f32; la.sphere_prims = sv.bvh_prims; la.spheres = sv.spheres; la.sphere_ids = sv.sphere_id;
@@ -445,48 +590,30 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const uint32_t trace_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfTraceWaves);
     // (grid-stride; 4 workgroups per CU are resident, and the fallback walk's HBM stack column is indexed by the resident lane)
     const uint32_t shade_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * 4u);
-    const size_t counter_bytes = (kWfLevelsPerSync + 2) * sizeof(unsigned long long);
-
-    hipError_t e = hipMemsetAsync(st.count, 0, counter_bytes, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(st.work, 0, counter_bytes, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, st);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-
-    uint32_t level = 0;                           // the path's level: draw / bounce indices
-    while (level < levels) {
-        const uint32_t chunk = levels - level < kWfLevelsPerSync ? levels - level : kWfLevelsPerSync;
-        for (uint32_t k = 0; k < chunk; ++k) {
-            // counters are indexed by the level's position in the chunk (k); the records by the parity of k as well
-            WfState sk = st;
-            sk.count = st.count + k; sk.work = st.work + k;
-            sk.rec[0] = st.rec[k & 1u]; sk.rec[1] = st.rec[(k + 1u) & 1u];
-            if (qn) {
-                if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, qnodes, ma, spill, spill_entries);
-                else hipLaunchKernelGGL((wf_trace_kernel<false, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, qnodes, ma, spill, spill_entries);
-            } else {
-                if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, nodes, ma, spill, spill_entries);
-                else hipLaunchKernelGGL((wf_trace_kernel<false, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level + k, counters, nodes, ma, spill, spill_entries);
-            }
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            if (deep) hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level + k, samples, counters, nodes, la, spill, spill_entries);
-            else hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level + k, samples, counters, nodes, la, spill, spill_entries);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+    auto generate = [&](const WfState &s0) {
+        hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, s0);
+        return hipGetLastError();
+    };
+    // level 0 as packets: the ray queue in 8x8 tiles, a tree the wave-uniform stack can hold
+    const bool packets = (sv.bvh_flags & 4u) != 0u && rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && !std::getenv("RTX_HIP_NO_PACKETS");
+    const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kPkWaves);
+    auto level_fn = [&](const WfState &sk, uint32_t level) {
+        if (level == 0u && packets) {
+            hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root);
+        } else if (qn) {
+            if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);
+            else hipLaunchKernelGGL((wf_trace_kernel<false, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);
+        } else {
+            if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, nodes, ma, spill, spill_entries);
+            else hipLaunchKernelGGL((wf_trace_kernel<false, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, nodes, ma, spill, spill_entries);
         }
-        level += chunk;
-        if (level >= levels) break;
-        // more levels allowed than one chunk: stop when the queue ran empty, else carry the queue length over
-        unsigned long long left = 0;
-        if ((e = hipMemcpyAsync(&left, st.count + chunk, sizeof left, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        if (left == 0) break;
-        if ((e = hipMemsetAsync(st.count, 0, counter_bytes, stream)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(st.work, 0, counter_bytes, stream)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(st.count, &left, sizeof left, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;      // (`left` is a stack variable)
-        if (chunk & 1u) std::swap(st.rec[0], st.rec[1]);                      // the next chunk's level 0 reads what this chunk's last level wrote
-    }
-    return hipSuccess;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (deep) hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, nodes, la, spill, spill_entries);
+        else hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, nodes, la, spill, spill_entries);
+        return hipGetLastError();
+    };
+    return wf_run_levels(st, levels, stream, generate, level_fn);
 }
 
 }  // namespace rtx
