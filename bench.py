@@ -67,10 +67,16 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                    "walk; trace_bvh_kernel when the tree holds triangles)",
                 5: "flat 4-wide BVH, regrouping schedule (trace_bvh_mesh_kernel: f32-only traversal step, exact f64 tests in the "
                    "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)",
-                6: "wavefront form for pure meshes: wf_trace_kernel (f32-only walk, 6 waves/SIMD) + wf_shade_kernel (f64) per bounce level"}
+                6: "wavefront form (what AUTO runs for a pure mesh whose tree stays in L2): per bounce level a walk kernel (f32 only; "
+                   "level 0: wf_trace_packet_kernel, one wave-uniform walk per 8x8 tile of primary rays; deeper levels: wf_trace_kernel, "
+                   "one walk per lane, lanes refilled from the level's queue) and wf_shade_kernel (f64: exact tests, ray_hit), ray state "
+                   "in HBM; the roofline object covers the whole sequence of one launch, wf_trace_packet_kernel is ~55 % of it"}
 # substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
 KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
-                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel"), 6: ("wf_trace_kernel",)}
+                 4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel", "trace_bvh_spheres_pool_kernel"),
+                 6: ("wf_trace_packet_kernel", "wf_trace_kernel", "wf_shade_kernel", "wf_generate_kernel",
+                     "wf_trace_spheres_kernel", "wf_shade_spheres_kernel", "wf_generate_spheres_kernel")}
+PMC_LEG_RENDERS = 2                # renders of the workload a --pmc-leg child does (pmc_leg)
 # lane-op prices of the algorithmic counts (what the chosen algorithm needs at least; f64 instructions issue at half rate
 # and count double).  box test: 6 fma + 9 min/max + 2 mul + 2 cmp; sphere filter: 7 fma + 1 sub; triangle filter: 16;
 # exact sphere test (sphere.rs:19-30): 17 f64 add/mul + sqrt + div (~14 f64 instructions each) = 45 f64 -> 90; exact
@@ -89,7 +95,7 @@ def parse():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json config benched as the primary workload")
     ap.add_argument("--spp", type=int, default=None, help="total rays per pixel (default: the config's own, 64 for C2)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: rays_per_pixel = spp * N (fixed rays per GPU); not the metric")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH lock-step, 5 BVH regroup, 6 wavefront (pure meshes)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto (default), 1 exact f64, 2 LDS sweep, 4 BVH lock-step, 5 BVH regroup, 6 wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lds-sweep", action="store_true", help="skip the secondary measurement of the LDS sweep kernel")
     ap.add_argument("--no-other-configs", action="store_true", help="skip C3 / C4 band / C5 band at N = 1")
@@ -148,7 +154,7 @@ def algorithmic(acc, cfg):
     seg = acc.segments / steps
     tri = cfg["scene"] == "triangles"
     out = {"segments_per_launch": seg / max(acc.launches / steps, 1)}
-    if acc.kernel in (4, 5):
+    if acc.kernel in (4, 5, 6):
         box, leaf, exact = acc.box / steps, (acc.filter - acc.box) / steps, acc.exact / steps
         ops = box * LANE_OPS["box"] + leaf * LANE_OPS["tri_filter" if tri else "sphere_filter"] + \
             exact * LANE_OPS["tri_exact" if tri else "sphere_exact"]
@@ -217,8 +223,12 @@ def roofline_of(acc, cfg, counters, source):
 # ---------------------------------------------------------------------------------------------------------------------
 # rocprofv3 counters, collected in this run
 # ---------------------------------------------------------------------------------------------------------------------
-def pmc_collect(leg, kernel_symbol, log):
-    """Runs `rocprofv3 --pmc ... -- python3 bench.py --pmc-leg LEG` once per counter pass; returns {counter: per launch}."""
+def pmc_collect(leg, kernel_symbol, log, launches_per_render=1):
+    """Runs `rocprofv3 --pmc ... -- python3 bench.py --pmc-leg LEG` once per counter pass; returns {counter: per launch}.
+
+    A "launch" is one trace call of the library (one sample batch): one kernel for the megakernels, the whole sequence of
+    generate / walk / shade kernels for the wavefront form -- the counters of every row that matches `kernel_symbol` are
+    summed and divided by the number of launches the child made (PMC_LEG_RENDERS renders x launches_per_render)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -239,21 +249,22 @@ def pmc_collect(leg, kernel_symbol, log):
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None, "rocprofv3 pass '%s' wrote no counter file" % name
-            acc, cnt, dur = {}, {}, []
+            acc, dur = {}, []
+            n_launches = float(PMC_LEG_RENDERS * max(int(round(launches_per_render)), 1))
             for f in files:
                 for r in csv.DictReader(open(f)):
                     if not any(sym in r.get("Kernel_Name", "") for sym in kernel_symbol):
                         continue
                     k = r["Counter_Name"]
                     acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
-                    cnt[k] = cnt.get(k, 0) + 1
                     if "Start_Timestamp" in r and "End_Timestamp" in r and k == counters[0]:
                         dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
             for k in counters:
                 if k in acc:
-                    got[k] = acc[k] / cnt[k]
+                    got[k] = acc[k] / n_launches
             if name == "fetch" and dur:
-                got["_pmc_launch_s"] = sum(dur) / len(dur)
+                got["_pmc_launch_s"] = sum(dur) / n_launches           # kernel time of one launch (all its kernels)
+                got["_pmc_kernels_per_launch"] = len(dur) / n_launches
             if not any(k in acc for k in counters):
                 return None, "no rows of %s in pass '%s'" % ("/".join(kernel_symbol), name)
     except Exception as e:                                     # noqa: BLE001 -- a profiler problem must not fail the bench
@@ -278,9 +289,9 @@ def stored_counters(key):
     return rec, "profiles/pmc_counters.json (kernel sources %s, %s)" % (d["kernel_source_hash"], d.get("collected", "?"))
 
 
-def counters_for(leg, kernel_symbol, allow_live, log):
+def counters_for(leg, kernel_symbol, allow_live, log, launches_per_render=1):
     if allow_live:
-        got, src = pmc_collect(leg, kernel_symbol, log)
+        got, src = pmc_collect(leg, kernel_symbol, log, launches_per_render)
         if got:
             return got, src
         log.append("live counters unavailable: " + src)
@@ -450,7 +461,7 @@ def main():
     if single and args.config == "C2" and not args.no_lds_sweep and acc.kernel != 2:
         handle.set_config(rcfg.with_kernel(rtx.RTX_KERNEL_MIXED))
         e2, acc2, full2, _ = run(handle, W, H, 0, 1, 1, 2, gather=False)
-        c2, src2 = counters_for("C2:%d:full:2" % spp, KERNEL_SYMBOL[2], live_pmc, log)
+        c2, src2 = counters_for("C2:%d:full:2" % spp, KERNEL_SYMBOL[2], live_pmc, log, acc2.launches / max(acc2.n, 1))
         lds = {"value": W * H * spp * 2 / e2 / 1e6, "unit": "Mrays/s", "ms_per_step": e2 / 2 * 1e3,
                "image_identical_to_value_kernel": bool(torch.equal(full, full2)) if full is not None else None,
                "roofline": roofline_of(acc2, cfg, c2, src2)}
@@ -475,7 +486,7 @@ def main():
             hnd.close()
             rays = n_rows * oc["w"] * s * 2
             leg = "%s:%d:%s:0" % (name, s, "band" if band else "full")
-            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, ("trace_",)), live_pmc, log)
+            cnt, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, ("trace_",)), live_pmc, log, a.launches / max(a.n, 1))
             others.append({
                 "config": name, "workload": "%s, %s at %d spp (the config names %d spp; Mrays/s is a rate)" % (
                     oc["name"], "the interleaved row band rank 0 of 8 owns (%d rows)" % n_rows if band else "full frame", s, oc["spp"]),
@@ -488,7 +499,8 @@ def main():
         steps = max(args.steps, 1)
         rays_per_step = W * H * spp
         value = rays_per_step * args.steps / elapsed / 1e6 if args.steps else 0.0
-        cnt, src = (counters_for("%s:%d:full:%d" % (args.config, spp, args.kernel), KERNEL_SYMBOL.get(acc.kernel, ("trace_",)), live_pmc, log)
+        cnt, src = (counters_for("%s:%d:full:%d" % (args.config, spp, args.kernel), KERNEL_SYMBOL.get(acc.kernel, ("trace_",)), live_pmc, log,
+                                 acc.launches / max(acc.n, 1))
                     if world == 1 else (None, "counters are collected at N = 1 only"))
         roof = roofline_of(acc, cfg, cnt, src)
         line = {

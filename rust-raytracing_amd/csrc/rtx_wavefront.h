@@ -26,14 +26,22 @@ struct WfRec {                        // 64 bytes: what the f32 walk needs of on
 };
 static_assert(sizeof(WfRec) == 64, "WfRec must be 64 bytes");
 
-struct WfCand { uint32_t count; uint32_t e[7]; };                 // 32 bytes per queue position
+struct WfCand { uint32_t count; uint32_t e[7]; };                 // 32 bytes per queue position: e[0..5] candidates, e[6] = the ray (ridx)
 static_assert(sizeof(WfCand) == 32, "WfCand must be 32 bytes");
 
-struct WfState {                      // structure-of-arrays over the launch's rays (capacity n), all on the device
+// The f64 state of a level's rays, structure-of-arrays in QUEUE order (slot p of the level's queue): the shade kernel reads
+// it with unit stride and writes the survivors' to the next level's set at their new slots.  (Indexed by ray instead,
+// the survivors thin out level by level and every 8-byte access drags a mostly dead line along: measured 1.4 KB of HBM
+// traffic per C3 segment in the shade kernel, which made it HBM-bound.)
+struct WfRays {
     double *pos[3], *dir[3], *res[3], *lig[3];
-    double *hit_t;                    // the pre-tested self-hit's distance, 0.0 = none
+    double *hit_t;                    // the pre-tested self-hit's distance, 0.0 = none            (meshes)
     uint32_t *left;                   // the triangle the ray just left (index in tris[]), kNone = none
-    WfRec *rec[2];                    // [0]: the records of the level being processed, [1]: where the next level's go
+};
+
+struct WfState {                      // capacity n (the launch's rays), all on the device
+    WfRays ray[2];                    // [0]: the level being processed, [1]: the next level's
+    WfRec *rec[2];                    // likewise: the f32 records of the walk
     WfCand *cand;
     uint2 *extra;                     // the level's overflow list: {queue position, candidate} of walks whose LDS queue ran full
     unsigned long long *xcount;       // xcount[0]: its length
@@ -126,12 +134,15 @@ inline void wf_carve(void *state_mem, uint64_t n, WfState &st)
 {
     char *p = static_cast<char *>(state_mem);
     auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-    for (int k = 0; k < 3; ++k) st.pos[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    for (int k = 0; k < 3; ++k) st.dir[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    for (int k = 0; k < 3; ++k) st.res[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    for (int k = 0; k < 3; ++k) st.lig[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
-    st.hit_t = reinterpret_cast<double *>(take(n * sizeof(double)));
-    st.left = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
+    for (int s = 0; s < 2; ++s) {
+        WfRays &r = st.ray[s];
+        for (int k = 0; k < 3; ++k) r.pos[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
+        for (int k = 0; k < 3; ++k) r.dir[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
+        for (int k = 0; k < 3; ++k) r.res[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
+        for (int k = 0; k < 3; ++k) r.lig[k] = reinterpret_cast<double *>(take(n * sizeof(double)));
+        r.hit_t = reinterpret_cast<double *>(take(n * sizeof(double)));
+        r.left = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
+    }
     st.rec[0] = reinterpret_cast<WfRec *>(take(n * sizeof(WfRec)));
     st.rec[1] = reinterpret_cast<WfRec *>(take(n * sizeof(WfRec)));
     st.cand = reinterpret_cast<WfCand *>(take(n * sizeof(WfCand)));
@@ -165,6 +176,7 @@ inline hipError_t wf_run_levels(WfState st, uint32_t levels, hipStream_t stream,
             WfState sk = st;
             sk.count = st.count + k; sk.work = st.work + k; sk.xcount = st.xcount + k;
             sk.rec[0] = st.rec[k & 1u]; sk.rec[1] = st.rec[(k + 1u) & 1u];
+            sk.ray[0] = st.ray[k & 1u]; sk.ray[1] = st.ray[(k + 1u) & 1u];
             if ((e = level_fn(sk, level + k)) != hipSuccess) return e;
         }
         level += chunk;
@@ -179,7 +191,7 @@ inline hipError_t wf_run_levels(WfState st, uint32_t levels, hipStream_t stream,
         if ((e = hipMemsetAsync(st.xcount, 0, counter_bytes, stream)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(st.count, &left, sizeof left, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;      // (`left` is a stack variable)
-        if (chunk & 1u) std::swap(st.rec[0], st.rec[1]);                      // the next chunk's level 0 reads what this chunk's last level wrote
+        if (chunk & 1u) { std::swap(st.rec[0], st.rec[1]); std::swap(st.ray[0], st.ray[1]); }                      // the next chunk's level 0 reads what this chunk's last level wrote
     }
     return hipSuccess;
 }

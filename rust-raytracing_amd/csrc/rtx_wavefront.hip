@@ -79,12 +79,9 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const SceneView *__res
     if (valid) {
         RayState r;
         gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
-        st.pos[0][i] = r.pos.x; st.pos[1][i] = r.pos.y; st.pos[2][i] = r.pos.z;
-        st.dir[0][i] = r.dir.x; st.dir[1][i] = r.dir.y; st.dir[2][i] = r.dir.z;
-        st.res[0][i] = 0.0; st.res[1][i] = 0.0; st.res[2][i] = 0.0;
-        st.lig[0][i] = 1.0; st.lig[1][i] = 1.0; st.lig[2][i] = 1.0;
-        st.hit_t[i] = 0.0;
-        st.left[i] = kNone;
+        const WfRays &rs = st.ray[0];                        // (result = 0, light = 1, no self-hit are implied at level 0)
+        rs.pos[0][i] = r.pos.x; rs.pos[1][i] = r.pos.y; rs.pos[2][i] = r.pos.z;
+        rs.dir[0][i] = r.dir.x; rs.dir[1][i] = r.dir.y; rs.dir[2][i] = r.dir.z;
         wf_make_rec(sv, r.pos, r.dir, vnorm(r.dir), __builtin_inff(), (uint32_t)i, w);
     } else {
         w.px = w.py = w.pz = w.dx = w.dy = w.dz = w.ix = w.iy = w.iz = w.nx = w.ny = w.nz = w.best_up = w.A = 0.f;
@@ -149,6 +146,7 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
                         k += 1;
                     }
                 }
+                c.e[6] = ridx;
                 c.count = ridx == kNone ? kWfDead : (overflow ? kWfFallback : (k | (extra ? kWfExtra : 0u)));
                 st.cand[pos] = c;
                 box_tests += nbox; leaf_filters += nleaf;
@@ -350,6 +348,7 @@ __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(
                     k += 1;
                 }
             }
+            c.e[6] = w.ridx;
             c.count = !valid ? kWfDead : (overflow ? kWfFallback : (k | (extra ? kWfExtra : 0u)));
             st.cand[p] = c;
         }
@@ -385,8 +384,8 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
     const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
     const unsigned long long n_queue = st.count[0];
-    const WfRec *__restrict__ recs = st.rec[0];
     WfRec *__restrict__ recs_out = st.rec[1];
+    const WfRays &rin = st.ray[0], &rout = st.ray[1];
     unsigned long long segs = 0, exact = 0, box_tests = 0, leaf_filters = 0;
 
     // grid-stride over the level's queue (the grid is sized for the launch's ray count; deep levels are short)
@@ -401,18 +400,21 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
         const bool have = (c.count & kWfDead) == 0u;
         bool next = false;
         WfRec w;
+        RayState r;
+        uint32_t lt = kNone;
+        double t0 = 0.0;
         if (have) {
-            const uint32_t ridx = recs[p].ridx;
-            RayState r;
-            r.pos = mk(st.pos[0][ridx], st.pos[1][ridx], st.pos[2][ridx]);
-            r.dir = mk(st.dir[0][ridx], st.dir[1][ridx], st.dir[2][ridx]);
+            const uint32_t ridx = c.e[6];
+            r.pos = mk(rin.pos[0][p], rin.pos[1][p], rin.pos[2][p]);
+            r.dir = mk(rin.dir[0][p], rin.dir[1][p], rin.dir[2][p]);
             const RayX rx = make_rayx(r.pos, r.dir);
             Hit h;
             hit_init(h);
             ++segs;
-            const uint32_t left = st.left[ridx];
-            const double ht = st.hit_t[ridx];
-            if (ht != 0.0) { h.t = ht; h.id = la.tris[left].id; h.kind = 2; h.local = left; }     // the pre-tested self-hit
+            if (level != 0u) {                     // the pre-tested self-hit (none at level 0)
+                const double ht = rin.hit_t[p];
+                if (ht != 0.0) { const uint32_t left = rin.left[p]; h.t = ht; h.id = la.tris[left].id; h.kind = 2; h.local = left; }
+            }
             bool covered = true;
             if (c.count & kWfFallback) {
 #ifdef RTX_WF_DIAG
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
                 }
             } else {
                 const uint32_t nc = c.count & 0xFFFFu;
-                const uint32_t n = nc < 7u ? nc : 7u;
+                const uint32_t n = nc < (uint32_t)kMeshQueue ? nc : (uint32_t)kMeshQueue;
                 if (c.count & kWfExtra) {          // this walk's queue ran full: the rest of its candidates are in the level's overflow list
                     const unsigned long long nx = st.xcount[0] < (unsigned long long)kWfExtraCap ? st.xcount[0] : (unsigned long long)kWfExtraCap;
                     for (unsigned long long i = 0; i < nx; ++i) {
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
                 }
 #pragma unroll 1
                 for (uint32_t e = 0; e < n; ++e) {
-                    const uint32_t idx = e == 0 ? c.e[0] : e == 1 ? c.e[1] : e == 2 ? c.e[2] : e == 3 ? c.e[3] : e == 4 ? c.e[4] : e == 5 ? c.e[5] : c.e[6];
+                    const uint32_t idx = e == 0 ? c.e[0] : e == 1 ? c.e[1] : e == 2 ? c.e[2] : e == 3 ? c.e[3] : e == 4 ? c.e[4] : c.e[5];
                     const uint32_t tk = la.tri_fidx[idx & ~kQueueTri];
                     double t;
                     if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
@@ -483,10 +485,10 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
             exact += sv.n_spheres + sv.n_planes + (sv.n_tri_filter - tri_sweep_from);
 
             // ---- render_ray's match arm + ray_hit (scene.rs:232-239, 260-278)
-            r.result = mk(st.res[0][ridx], st.res[1][ridx], st.res[2][ridx]);
+            r.result = level == 0u ? mk(0.0, 0.0, 0.0) : mk(rin.res[0][p], rin.res[1][p], rin.res[2][p]);
             bool done = true;
             if (h.id != kNone) {
-                r.light = mk(st.lig[0][ridx], st.lig[1][ridx], st.lig[2][ridx]);
+                r.light = level == 0u ? mk(1.0, 1.0, 1.0) : mk(rin.lig[0][p], rin.lig[1][p], rin.lig[2][p]);
                 uint32_t pl = 0, smp = 0;
                 if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                 else ray_index_to_pixel(rv, ridx, pl, smp);
@@ -501,28 +503,30 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
             if (done) {
                 store_sample(samples, rv, ridx, r.result);
             } else {
-                st.pos[0][ridx] = r.pos.x; st.pos[1][ridx] = r.pos.y; st.pos[2][ridx] = r.pos.z;
-                st.dir[0][ridx] = r.dir.x; st.dir[1][ridx] = r.dir.y; st.dir[2][ridx] = r.dir.z;
-                st.res[0][ridx] = r.result.x; st.res[1][ridx] = r.result.y; st.res[2][ridx] = r.result.z;
-                st.lig[0][ridx] = r.light.x; st.lig[1][ridx] = r.light.y; st.lig[2][ridx] = r.light.z;
                 // the next segment: the reference's self-hit is tested here, exactly (rtx_bvh_mesh.hip), and bounds the walk
                 const RayX rn = make_rayx(r.pos, r.dir);
-                const uint32_t lt = h.kind == 2u ? h.local : kNone;
-                double t0 = 0.0;
+                lt = h.kind == 2u ? h.local : kNone;
                 float bu = __builtin_inff();
                 if (lt != kNone) {
                     double t;
                     if (triangle_distance(la.tris[lt], rn, &t) && is_normal_positive(t)) { t0 = t; bu = round_up32(t); }
                     exact += 1;
                 }
-                st.left[ridx] = lt;
-                st.hit_t[ridx] = t0;
                 wf_make_rec(sv, r.pos, r.dir, rn.dirn, bu, ridx, w);
                 next = true;
             }
         }
+        // the survivors move to the next level's queue: record and state at their new slot, unit stride across the block
         const unsigned long long slot = wf_append_block(&st.count[1], next, lds_append, it);
-        if (next) recs_out[slot] = w;
+        if (next) {
+            recs_out[slot] = w;
+            rout.pos[0][slot] = r.pos.x; rout.pos[1][slot] = r.pos.y; rout.pos[2][slot] = r.pos.z;
+            rout.dir[0][slot] = r.dir.x; rout.dir[1][slot] = r.dir.y; rout.dir[2][slot] = r.dir.z;
+            rout.res[0][slot] = r.result.x; rout.res[1][slot] = r.result.y; rout.res[2][slot] = r.result.z;
+            rout.lig[0][slot] = r.light.x; rout.lig[1][slot] = r.light.y; rout.lig[2][slot] = r.light.z;
+            rout.left[slot] = lt;
+            rout.hit_t[slot] = t0;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -541,14 +545,14 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
-// Per ray of a launch: 12 f64 of state + the self-hit's distance + the triangle it left + two 64-byte records + 32 bytes of
-// candidates; per level three u64 counters; the overflow list.
+// Per ray of a launch: two sets of {12 f64 of state, the self-hit's distance, the triangle it left}, two 64-byte records,
+// 32 bytes of candidates; per level three u64 counters; the overflow list.
 size_t wavefront_state_bytes(uint64_t n_rays, uint32_t levels)
 {
     (void)levels;
-    return (size_t)n_rays * (13 * sizeof(double) + sizeof(uint32_t) + 2 * sizeof(WfRec) + sizeof(WfCand)) +
+    return (size_t)n_rays * (2 * (13 * sizeof(double) + sizeof(uint32_t)) + 2 * sizeof(WfRec) + sizeof(WfCand)) +
            (size_t)(3 * kWfLevelsPerSync + 12) * sizeof(unsigned long long) + (size_t)kWfExtraCap * sizeof(uint2) +
-           40 * 256;                              // (every array starts on a 256-byte boundary)
+           64 * 256;                              // (every array starts on a 256-byte boundary)
 }
 
 uint32_t wavefront_levels(const SceneView &sv)

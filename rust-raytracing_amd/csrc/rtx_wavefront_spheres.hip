@@ -34,7 +34,7 @@ struct WfSphRec {                     // 64 bytes: what the f32 walk needs of on
     uint32_t ridx;                    // the ray (index in the launch's queue order)
 };
 static_assert(sizeof(WfSphRec) == sizeof(WfRec), "WfSphRec shares WfRec's slots");
-// WfCand of this form: count (| kWfFallback), e[0] = ridx, e[1..4] = local sphere indices
+// WfCand of this form: count (| kWfFallback), e[0..3] = local sphere indices, e[6] = ridx
 
 __device__ __forceinline__ void wf_make_sph_rec(const SceneView &sv, const V3 &pos, const V3 &dir, const V3 &dirn, uint32_t ridx,
                                                 WfSphRec &w)
@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void wf_generate_spheres_kernel(const SceneVie
     if (valid) {
         RayState r;
         gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
-        st.pos[0][i] = r.pos.x; st.pos[1][i] = r.pos.y; st.pos[2][i] = r.pos.z;
-        st.dir[0][i] = r.dir.x; st.dir[1][i] = r.dir.y; st.dir[2][i] = r.dir.z;
+        const WfRays &rs = st.ray[0];
+        rs.pos[0][i] = r.pos.x; rs.pos[1][i] = r.pos.y; rs.pos[2][i] = r.pos.z;
+        rs.dir[0][i] = r.dir.x; rs.dir[1][i] = r.dir.y; rs.dir[2][i] = r.dir.z;
         wf_make_sph_rec(sv, r.pos, r.dir, vnorm(r.dir), (uint32_t)i, w);
     } else {
         w.ix = w.iy = w.iz = w.nx = w.ny = w.nz = w.px = w.py = w.pz = w.dx = w.dy = w.dz = w.Kg = w.c0 = w.slack = 0.f;
@@ -127,15 +128,15 @@ __global__ __launch_bounds__(kBvhThreads, kWfSphWaves) void wf_trace_spheres_ker
             if (!walking && have) {
                 WfCand c;
                 uint32_t k = 0;
-                c.e[0] = ridx;
 #pragma unroll
-                for (int e = 1; e < 7; ++e) c.e[e] = 0u;
+                for (int e = 0; e < 6; ++e) c.e[e] = 0u;
+                c.e[6] = ridx;
 #pragma unroll
                 for (int e = 0; e < kSphQueue; ++e) {
                     if ((uint32_t)e < qcnt && __uint_as_float(lq[(size_t)(kSphQueue + e) * kBvhThreads + tid]) <= best_up) {
                         const uint32_t v = lq[(size_t)e * kBvhThreads + tid];
-                        c.e[1] = k == 0u ? v : c.e[1]; c.e[2] = k == 1u ? v : c.e[2];
-                        c.e[3] = k == 2u ? v : c.e[3]; c.e[4] = k == 3u ? v : c.e[4];
+                        c.e[0] = k == 0u ? v : c.e[0]; c.e[1] = k == 1u ? v : c.e[1];
+                        c.e[2] = k == 2u ? v : c.e[2]; c.e[3] = k == 3u ? v : c.e[3];
                         k += 1;
                     }
                 }
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_spheres_kernel(const 
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
     const unsigned long long n_queue = st.count[0];
     WfSphRec *__restrict__ recs_out = reinterpret_cast<WfSphRec *>(st.rec[1]);
+    const WfRays &rin = st.ray[0], &rout = st.ray[1];
     unsigned long long segs = 0, exact = 0, box_tests = 0, leaf_filters = 0;
 
     // grid-stride over the level's queue (the grid is sized for the launch's ray count; deep levels are short)
@@ -215,11 +217,11 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_spheres_kernel(const 
         const bool have = (c.count & kWfDead) == 0u;
         bool next = false;
         WfSphRec w;
+        RayState r;
         if (have) {
-            const uint32_t ridx = c.e[0];
-            RayState r;
-            r.pos = mk(st.pos[0][ridx], st.pos[1][ridx], st.pos[2][ridx]);
-            r.dir = mk(st.dir[0][ridx], st.dir[1][ridx], st.dir[2][ridx]);
+            const uint32_t ridx = c.e[6];
+            r.pos = mk(rin.pos[0][p], rin.pos[1][p], rin.pos[2][p]);
+            r.dir = mk(rin.dir[0][p], rin.dir[1][p], rin.dir[2][p]);
             const RayX rx = make_rayx(r.pos, r.dir);
             Hit h;
             hit_init(h);
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_spheres_kernel(const 
                 const uint32_t n = c.count < (uint32_t)kSphQueue ? c.count : (uint32_t)kSphQueue;
 #pragma unroll 1
                 for (uint32_t e = 0; e < n; ++e) {
-                    const uint32_t idx = e == 0 ? c.e[1] : e == 1 ? c.e[2] : e == 2 ? c.e[3] : c.e[4];
+                    const uint32_t idx = e == 0 ? c.e[0] : e == 1 ? c.e[1] : e == 2 ? c.e[2] : c.e[3];
                     double t;
                     if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
                 }
@@ -255,10 +257,10 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_spheres_kernel(const 
             exact += sv.n_planes + sv.n_tri_filter;
 
             // ---- render_ray's match arm + ray_hit (scene.rs:232-239, 260-278)
-            r.result = level == 0u ? mk(0.0, 0.0, 0.0) : mk(st.res[0][ridx], st.res[1][ridx], st.res[2][ridx]);
+            r.result = level == 0u ? mk(0.0, 0.0, 0.0) : mk(rin.res[0][p], rin.res[1][p], rin.res[2][p]);
             bool done = true;
             if (h.id != kNone) {
-                r.light = level == 0u ? mk(1.0, 1.0, 1.0) : mk(st.lig[0][ridx], st.lig[1][ridx], st.lig[2][ridx]);
+                r.light = level == 0u ? mk(1.0, 1.0, 1.0) : mk(rin.lig[0][p], rin.lig[1][p], rin.lig[2][p]);
                 uint32_t pl = 0, smp = 0;
                 if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                 else ray_index_to_pixel(rv, ridx, pl, smp);
@@ -273,16 +275,19 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_spheres_kernel(const 
             if (done) {
                 store_sample(samples, rv, ridx, r.result);
             } else {
-                st.pos[0][ridx] = r.pos.x; st.pos[1][ridx] = r.pos.y; st.pos[2][ridx] = r.pos.z;
-                st.dir[0][ridx] = r.dir.x; st.dir[1][ridx] = r.dir.y; st.dir[2][ridx] = r.dir.z;
-                st.res[0][ridx] = r.result.x; st.res[1][ridx] = r.result.y; st.res[2][ridx] = r.result.z;
-                st.lig[0][ridx] = r.light.x; st.lig[1][ridx] = r.light.y; st.lig[2][ridx] = r.light.z;
                 wf_make_sph_rec(sv, r.pos, r.dir, vnorm(r.dir), ridx, w);
                 next = true;
             }
         }
+        // the survivors move to the next level's queue: record and state at their new slot, unit stride across the block
         const unsigned long long slot = wf_append_block(&st.count[1], next, lds_append, it);
-        if (next) recs_out[slot] = w;
+        if (next) {
+            recs_out[slot] = w;
+            rout.pos[0][slot] = r.pos.x; rout.pos[1][slot] = r.pos.y; rout.pos[2][slot] = r.pos.z;
+            rout.dir[0][slot] = r.dir.x; rout.dir[1][slot] = r.dir.y; rout.dir[2][slot] = r.dir.z;
+            rout.res[0][slot] = r.result.x; rout.res[1][slot] = r.result.y; rout.res[2][slot] = r.result.z;
+            rout.lig[0][slot] = r.light.x; rout.lig[1][slot] = r.light.y; rout.lig[2][slot] = r.light.z;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -268,19 +268,23 @@ def test_spheres_kernel_paths(gpu, oracle):
     C2 does not reach: a tree deep enough for the HBM stack column, origins far outside the scene (f64 slab walk) and
     beyond any walk (every sphere tested), axis-parallel rays, more coincident candidates than the 4-entry queue holds,
     nested shells (every shell a certain hit, the nearest wins), and spheres whose radius is at the f32 resolution of
-    their centre (no certain hit exists: the bounds only ever add candidates)."""
+    their centre (no certain hit exists: the bounds only ever add candidates).  The same step under its two other
+    schedules runs beside it: RTX_KERNEL_BVH_REGROUP (trace_bvh_spheres_pool_kernel: a pool of rays per lane, waiting lanes
+    served together) and RTX_KERNEL_WAVEFRONT (walk / shade kernels per bounce level, far origins with the f32 slack)."""
     import torch
     from rust_raytracing_amd import scenes
 
     def both(objs, cam, w=64, h=36, spp=2, **cfg):
         out = []
-        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_EXACT):
+        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_KERNEL_EXACT):
             hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
             hnd.close()
+            assert st.kernel == kern
             out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
-        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+        for o in out[:-1]:
+            assert np.array_equal(o[0], out[-1][0]) and o[1] == out[-1][1]
         return out[0]
 
     deep = scenes.random_spheres(300000, 11)
@@ -313,6 +317,16 @@ def test_spheres_kernel_paths(gpu, oracle):
     tiny["geom"][:, 3] *= 2e-5                                               # r ~ 1e-5 at |c| ~ 100: r is 1-2 ulp(f32) of the centre
     tiny["geom"][:, 0] = 10.0 + (tiny["geom"][:, 0] - 10.0) * 1e-3            # a thin slab the rays must cross
     both(tiny, scenes.CAMERA, w=128, h=72)
+    both(c2, scenes.CAMERA, w=67, h=35, spp=3)                               # partial tiles (dead queue slots), odd sample count
+    bouncy = co.copy()
+    bouncy["base_color"] = 0.97; bouncy["emission_color"] *= 0.05              # paths survive: more levels than one host-side chunk
+    both(bouncy, scenes.CAMERA, max_bounces=40)
+    both(bouncy, scenes.CAMERA, max_bounces=0)
+    os.environ["RTX_HIP_SCRATCH_MB"] = "1"                                     # one sample per batch
+    try:
+        both(co, scenes.CAMERA, spp=3)
+    finally:
+        del os.environ["RTX_HIP_SCRATCH_MB"]
 
 
 def test_mesh_kernel_paths(gpu, oracle):
@@ -374,6 +388,47 @@ def test_mesh_kernel_paths(gpu, oracle):
     needles["geom"][:, 6:9] = needles["geom"][:, 0:3] + (needles["geom"][:, 3:6] - needles["geom"][:, 0:3]) * 0.5 + 1e-5   # area ~ 1e-5
     needles["geom"][::2, 2] = needles["geom"][::2, 5] = needles["geom"][::2, 8]                                             # every other one edge-on in z
     both(needles, scenes.CAMERA, w=96, h=54)
+
+
+def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
+    """AUTO on a pure (x, y)-footprint mesh whose tree fits the L2s, with >= 2^22 rays: RTX_KERNEL_WAVEFRONT, whose level 0
+    walks each 8x8 tile of primary rays as one packet (wf_trace_packet_kernel).  Same bits as the regrouping megakernel,
+    as the wavefront form with per-lane walks at level 0 (RTX_HIP_NO_PACKETS), and the oracle on scattered pixels; below
+    the ray count AUTO stays with the megakernel.  A frame that does not divide into tiles and a row band are included."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.light_every(scenes.compact(scenes.random_triangles(30000, 8), k=0.06, x0=5.0))
+    w, h, spp = 517, 509, 16                                                  # 4.21e6 rays, partial tiles on both edges
+
+    def render(kernel, rb=0, rs=1, rows=h, **env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hnd = hip_scene(gpu, objs, kernel=kernel, rays_per_pixel=spp, seed=42).upload(0)
+            buf = torch.zeros((rows, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, rb, rs, rows, buf.data_ptr())
+            hnd.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        return buf.cpu().numpy(), st
+
+    auto, st = render(gpu.RTX_KERNEL_AUTO)
+    assert st.kernel == gpu.RTX_KERNEL_WAVEFRONT
+    mega, stm = render(gpu.RTX_KERNEL_BVH_REGROUP)
+    assert np.array_equal(auto, mega) and st.segments == stm.segments
+    lanes, stl = render(gpu.RTX_KERNEL_WAVEFRONT, RTX_HIP_NO_PACKETS="1")
+    assert np.array_equal(auto, lanes) and stl.box_tests < st.box_tests        # (a packet tests the union of its rays' nodes)
+    xs, ys = _scattered_pixels(auto, 150, 40, seed=3)
+    ref = oracle.render_pixels(oracle.make_scene(objs, DEFAULT_CAM, rays_per_pixel=spp, seed=42), w, h, xs, ys)
+    assert max_abs_diff(auto[ys, xs], ref) <= ATOL
+    band, stb = render(gpu.RTX_KERNEL_WAVEFRONT, rb=3, rs=8, rows=len(range(3, h, 8)))
+    assert np.array_equal(band, auto[3::8])
+    small, sts = render(gpu.RTX_KERNEL_AUTO, rows=h // 2)                       # 2.1e6 rays: the megakernel
+    assert sts.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(small, auto[:h // 2])
 
 
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
@@ -790,7 +845,7 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
     (= the regrouping BVH kernel).  (1) two renders are bit-identical, (2) segments within [rays, 11 rays], (3) 300+
     scattered pixels -- corners, edge columns, the brightest pixels, random ones -- equal the oracle's
     (rtxo_render_pixels: every triangle tested per segment, triangle.rs:108-127, scene.rs:243-251) within ATOL,
-    (4) the lock-step BVH kernel produces the same frame bit for bit."""
+    (4) the lock-step BVH kernel and the wavefront form (packets at level 0) produce the same frame bit for bit."""
     import torch
     from rust_raytracing_amd import scenes
     objs = scenes.random_triangles(100000, 2)
@@ -809,6 +864,10 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
     buf.zero_()
     st2 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
     assert np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
+    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT))       # (what AUTO runs from 2^22 rays on)
+    buf.zero_()
+    st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    assert st3.kernel == gpu.RTX_KERNEL_WAVEFRONT and np.array_equal(a, buf.cpu().numpy()) and st3.segments == st.segments
     hnd.close()
     xs, ys = _scattered_pixels(a, 200, 100, seed=11)
     assert len(xs) >= 256
