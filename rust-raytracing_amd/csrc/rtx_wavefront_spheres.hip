@@ -19,8 +19,11 @@
 
 namespace rtx {
 
-constexpr int kWfSphWaves = 4;                                    // workgroups per CU of the walk kernel
-constexpr int kWfSphStack = 30;                                   // LDS stack entries per lane (+ sink row + 2 * kSphQueue queue rows)
+#ifndef RTX_WF_SPH_WAVES
+#define RTX_WF_SPH_WAVES 4
+#endif
+constexpr int kWfSphWaves = RTX_WF_SPH_WAVES;                     // workgroups per CU of the walk kernel
+constexpr int kWfSphStack = 160 / kWfSphWaves - 2 - 2 * kSphQueue;   // LDS stack entries per lane (+ sink row + 2 * kSphQueue queue rows)
 #ifndef RTX_WF_SPH_SERVICE
 #define RTX_WF_SPH_SERVICE 16
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak: the tree kernels (BVH lock-step, BVH regroup) and the LDS sweep against the exhaustive f64 kernel, bit for bit, on
+"""Soak: the tree kernels (BVH lock-step, BVH regroup, wavefront form) and the LDS sweep against the exhaustive f64 kernel, bit for bit, on
 the full-size C2 / C3 scenes from several cameras (outside, inside the cloud, looking along each axis).  Prints one line
 per (scene, camera) with the number of segments compared; exits non-zero on the first difference."""
 import sys, os, math
@@ -39,7 +39,7 @@ def run(name, objs, w, h, spp, kernels):
 
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-    K = [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_MIXED]
+    K = [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT, rtx.RTX_KERNEL_MIXED]
     n = run("C2 10k spheres", scenes.random_spheres(10000, 1), int(1920 * scale), int(1080 * scale), 1, K)
     n += run("C3 100k triangles", scenes.random_triangles(100000, 2), int(960 * scale), int(540 * scale), 1, K)
     n += run("mixed 3k spheres + 30k triangles + 2 planes",
@@ -50,5 +50,5 @@ if __name__ == "__main__":
              np.concatenate([aam, scenes.random_spheres(2000, 13)]), int(960 * scale), int(540 * scale), 1, K)
     if "c5" in sys.argv[2:]:                      # 1M triangles: the exhaustive kernel needs ~10 s per camera at this size
         n += run("C5 1M triangles", scenes.random_triangles(1000000, 3, box=2.0), int(480 * scale), int(270 * scale), 1,
-                 [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP])
+                 [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT])
     print("soak ok:", n, "segments compared bit for bit")
