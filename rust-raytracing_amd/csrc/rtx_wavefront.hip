@@ -36,7 +36,11 @@ constexpr uint32_t kWfService = RTX_WF_SERVICE;                   // lanes of a 
 #ifndef RTX_WF_TRACE_WAVES
 #define RTX_WF_TRACE_WAVES 4
 #endif
-constexpr int kWfTraceWaves = RTX_WF_TRACE_WAVES;                                  // workgroups per CU of the walk kernel
+constexpr int kWfTraceWaves = RTX_WF_TRACE_WAVES;
+#ifndef RTX_WF_SHADE_WAVES
+#define RTX_WF_SHADE_WAVES 4
+#endif
+constexpr int kWfShadeWaves = RTX_WF_SHADE_WAVES;                 // workgroups per CU of the shade kernel                                  // workgroups per CU of the walk kernel
 constexpr int kWfStack = 160 / kWfTraceWaves - 1 - 2 * kMeshQueue;   // 13 LDS stack entries per lane, the HBM column behind them
 
 __device__ __forceinline__ void wf_make_rec(const SceneView &sv, const V3 &pos, const V3 &dir, const V3 &dirn, float best_up,
@@ -368,25 +372,19 @@ __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(
 }
 
 // ---- closest_object's exact part, ray_hit, the next segment's set-up ---------------------------------------------------------
-template <bool SPILL>
-__global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
+__global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
                                                                   const WfState st, uint32_t level, double *__restrict__ samples,
-                                                                  Counters *__restrict__ ctr, const float4 *__restrict__ nodes,
-                                                                  const LeafArrays la, uint32_t *__restrict__ spill,
-                                                                  uint32_t spill_entries)
+                                                                  Counters *__restrict__ ctr, const LeafArrays la)
 {
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
-    __shared__ uint32_t lds_stack[kBvh4StackEntries + 1][kBvhThreads];       // the fallback walk's (round 1's bvh_traverse)
-    __shared__ uint32_t lds_q[kBvhQueue][kBvhThreads];
     __shared__ uint32_t lds_append[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
     const unsigned long long n_queue = st.count[0];
     WfRec *__restrict__ recs_out = st.rec[1];
     const WfRays &rin = st.ray[0], &rout = st.ray[1];
-    unsigned long long segs = 0, exact = 0, box_tests = 0, leaf_filters = 0;
+    unsigned long long segs = 0, exact = 0;
 
     // grid-stride over the level's queue (the grid is sized for the launch's ray count; deep levels are short)
     // (block-uniform trip count: the append is one atomic per workgroup iteration)
@@ -417,33 +415,9 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
             }
             bool covered = true;
             if (c.count & kWfFallback) {
-#ifdef RTX_WF_DIAG
-                atomicAdd(&ctr[0].pad_, 1ull + ((unsigned long long)(level == 0u) << 32));
-#endif
+                // no walk was possible (an origin beyond 2^27 x origin_limit, NaN) or the level's overflow list was full:
+                // every triangle, exactly
                 covered = false;
-                const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
-                                         __builtin_fabsf((float)r.pos.z));
-                const bool in32 = omax <= sv.bvh_origin_limit, in64 = !in32 && omax <= sv.bvh_origin_limit * kBvhRange64;
-                if (in32 || in64) {                // round 1's walk: exact tests interleaved, f32 or f64 slab test
-                    FilterParams fpar;
-                    TriFilterParams tpar;
-                    filter_idle(fpar);
-                    tri_filter_from_ray(sv, r.pos, r.dir, tpar);
-                    bool ovf = false;
-                    unsigned long long unused_steps = 0;
-                    if (in32) {
-                        Ray32 q;
-                        make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
-                        bvh_traverse<true, SPILL>(nodes, la, q, fpar, tpar, rx, sv.bvh_root, ovf, h, &lds_stack[0][0], &lds_q[0][0], tid,
-                                                  spill, spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, unused_steps);
-                    } else {
-                        Ray64 q;
-                        make_ray64(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
-                        bvh_traverse<true, SPILL>(nodes, la, q, fpar, tpar, rx, sv.bvh_root, ovf, h, &lds_stack[0][0], &lds_q[0][0], tid,
-                                                  spill, spill_entries, spill_stride, glane, box_tests, leaf_filters, exact, unused_steps);
-                    }
-                    covered = !ovf;
-                }
             } else {
                 const uint32_t nc = c.count & 0xFFFFu;
                 const uint32_t n = nc < (uint32_t)kMeshQueue ? nc : (uint32_t)kMeshQueue;
@@ -532,15 +506,11 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_kernel(const SceneVie
     for (int off = 32; off > 0; off >>= 1) {
         segs += __shfl_xor(segs, off, 64);
         exact += __shfl_xor(exact, off, 64);
-        box_tests += __shfl_xor(box_tests, off, 64);
-        leaf_filters += __shfl_xor(leaf_filters, off, 64);
     }
     if (lane == 0) {
         const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
         if (segs) atomicAdd(&ctr[shard].segments, segs);
         if (exact) atomicAdd(&ctr[shard].exact_tests, exact);
-        if (box_tests + leaf_filters) atomicAdd(&ctr[shard].filter_tests, box_tests + leaf_filters);
-        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);
     }
 }
 
@@ -568,7 +538,7 @@ uint32_t wavefront_spill_entries(const SceneView &sv)
 
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus)
 {
-    // one column per resident lane of whichever kernel walks: the walk kernel at kWfTraceWaves, the shade kernel's fallback at 4
+    // one column per resident lane of the walk kernel
     return (size_t)wavefront_spill_entries(sv) * (size_t)n_cus * kWfTraceWaves * kBvhThreads * sizeof(uint32_t);
 }
 
@@ -592,8 +562,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const float4 *qnodes = reinterpret_cast<const float4 *>(sv.bvh_qnodes);
     const bool qn = (sv.bvh_flags & 8u) != 0u && !std::getenv("RTX_HIP_NO_QNODES");
     const uint32_t trace_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfTraceWaves);
-    // (grid-stride; 4 workgroups per CU are resident, and the fallback walk's HBM stack column is indexed by the resident lane)
-    const uint32_t shade_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * 4u);
+    const uint32_t shade_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfShadeWaves);   // (grid-stride)
     auto generate = [&](const WfState &s0) {
         hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, s0);
         return hipGetLastError();
@@ -613,8 +582,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        if (deep) hipLaunchKernelGGL(wf_shade_kernel<true>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, nodes, la, spill, spill_entries);
-        else hipLaunchKernelGGL(wf_shade_kernel<false>, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, nodes, la, spill, spill_entries);
+        hipLaunchKernelGGL(wf_shade_kernel, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, la);
         return hipGetLastError();
     };
     return wf_run_levels(st, levels, stream, generate, level_fn);
