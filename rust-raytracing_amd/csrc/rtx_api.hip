@@ -666,13 +666,11 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (h->sv.n_bvh_nodes != 0 && outside_tree <= 64) {
             const bool mesh = (h->sv.bvh_flags & 2u) != 0u && h->sv.n_tri_tree >= 1024u;
             kernel = mesh ? RTX_KERNEL_BVH_REGROUP : RTX_KERNEL_BVH;
-            // a pure (x, y)-footprint mesh whose tree stays in the L2s, rendered with enough rays to fill the per-level
-            // kernels: the wavefront form, whose level 0 walks a tile's primary rays as one packet (measured on C3,
-            // 100k triangles: 1920x1080x8 304 vs 166 Mrays/s, 960x540x8 197 vs 163, 480x270x8 89 vs 132; on C5, 1M
-            // triangles = 130 MB of nodes and records, 41 vs 44)
-            const uint64_t tree_bytes = (uint64_t)h->sv.n_bvh_nodes * (sizeof(Bvh4Node) + sizeof(BvhQNode)) + (uint64_t)h->sv.n_tri_tree * 64u;
-            if (mesh && (h->sv.bvh_flags & 4u) != 0u && tree_bytes <= (32ull << 20) && (uint64_t)npix * spp >= (1ull << 22) &&
-                !std::getenv("RTX_HIP_NO_TILES"))
+            // a pure (x, y)-footprint mesh rendered with >= 2^20 rays: the wavefront form, whose level 0 walks a tile's
+            // primary rays as one packet; the regrouping megakernel continues from its queue, or the deeper levels stay in
+            // that form too (rtx_wavefront.hip).  Measured on C3 (100k triangles), wavefront vs megakernel: 1920x1080x8
+            // 315 vs 166 Mrays/s, 960x540x8 272 vs 163, 480x270x8 160 vs 130; C5 band (1M triangles) 57 vs 44
+            if (mesh && (h->sv.bvh_flags & 4u) != 0u && (uint64_t)npix * spp >= (1ull << 20) && !std::getenv("RTX_HIP_NO_TILES"))
                 kernel = RTX_KERNEL_WAVEFRONT;
         } else {
             kernel = RTX_KERNEL_MIXED;

@@ -34,17 +34,22 @@ namespace rtx {
 #endif
 constexpr uint32_t kMeshWaves = RTX_MESH_WAVES;   // waves per SIMD (= workgroups per CU)
 constexpr int kMeshStack = (RTX_MESH_WAVES <= 4 ? 39 : 160 / RTX_MESH_WAVES) - 1 - 2 * kMeshQueue;   // LDS stack entries per lane: (entries + 1 sink row + 2 * kMeshQueue) KB per workgroup
-template <bool SPILL, int PLAIN>
+// QUEUE: the rays are not generated here but taken from `src`, a queue of rays in flight at path level 1 (the hybrid of
+// rtx_wavefront.hip: the primary rays of a mesh whose tree exceeds the L2s walk as packets there, and everything after the
+// first hit runs here, where the f64 phases of other waves fill the waits of the per-lane walks).
+template <bool SPILL, int PLAIN, bool QUEUE>
 __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel(const SceneView *__restrict__ svp,
                                                                                  const RowsView *__restrict__ rvp,
                                                                                  double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                                  unsigned long long *__restrict__ work_counter,
                                                                                  const float4 *__restrict__ nodes, const LeafArrays la,
                                                                                  const MeshArrays ma, uint32_t *__restrict__ spill,
-                                                                                 uint32_t spill_entries, uint32_t thresh)
+                                                                                 uint32_t spill_entries, uint32_t thresh,
+                                                                                 const MeshRaySource src)
 {
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
+    const unsigned long long n_rays = QUEUE ? *src.count : rv.n_rays;
     __shared__ uint32_t lds_stack[kMeshStack + 1][kBvhThreads];        // + the sink row of the branch-free pushes
     __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];            // candidate entries, then their t_lo
     uint32_t *const ls = &lds_stack[0][0];
@@ -149,22 +154,41 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
                 base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
                        __builtin_amdgcn_readfirstlane((uint32_t)base);
                 wave_next = base;
-                wave_end = base + rv.grab < rv.n_rays ? base + rv.grab : rv.n_rays;
-                if (base >= rv.n_rays) { queue_empty = true; wave_next = wave_end = 0; break; }
+                wave_end = base + rv.grab < n_rays ? base + rv.grab : n_rays;
+                if (base >= n_rays) { queue_empty = true; wave_next = wave_end = 0; break; }
             }
             if (state == S_IDLE) {
                 const unsigned long long my = wave_next + bvh_mbcnt(idle_mask);
                 bool valid = my < wave_end;
                 uint32_t pl = 0, smp = 0;
-                if (valid) {
-                    if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
-                    else ray_index_to_pixel(rv, my, pl, smp);
-                }
-                if (valid) {
-                    gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
-                    ridx = (uint32_t)my;                                          // (the host keeps rv.n_rays below 2^32)
-                    left_tri = kNone;
-                    state = S_SETUP;
+                if constexpr (QUEUE) {
+                    if (valid) {                       // a ray in flight: its state as wf_shade_kernel left it after the first hit
+                        ridx = src.ridx[(size_t)my * src.ridx_stride];
+                        if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
+                        else ray_index_to_pixel(rv, ridx, pl, smp);
+                        const uint32_t k = pl / rv.width, x = pl - k * rv.width;
+                        const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                        r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
+                        r.bounce = 1u;
+                        r.draw = 8u;
+                        r.pos = mk(src.pos[0][my], src.pos[1][my], src.pos[2][my]);
+                        r.dir = mk(src.dir[0][my], src.dir[1][my], src.dir[2][my]);
+                        r.result = mk(src.res[0][my], src.res[1][my], src.res[2][my]);
+                        r.light = mk(src.lig[0][my], src.lig[1][my], src.lig[2][my]);
+                        left_tri = src.left[my];
+                        state = S_SETUP;
+                    }
+                } else {
+                    if (valid) {
+                        if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
+                        else ray_index_to_pixel(rv, my, pl, smp);
+                    }
+                    if (valid) {
+                        gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
+                        ridx = (uint32_t)my;                                          // (the host keeps rv.n_rays below 2^32)
+                        left_tri = kNone;
+                        state = S_SETUP;
+                    }
                 }
             }
             const unsigned long long taken = (unsigned long long)__popcll(idle_mask);
@@ -283,9 +307,9 @@ size_t bvh_mesh_spill_bytes(const SceneView &sv, int n_cus)
     return (size_t)bvh_mesh_spill_entries(sv) * (size_t)n_cus * kMeshWaves * kBvhThreads * sizeof(uint32_t);
 }
 
-hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
-                                 double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                 hipStream_t stream)
+static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv, double *samples,
+                              Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus, hipStream_t stream,
+                              const MeshRaySource *src)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kMeshWaves;
@@ -306,15 +330,34 @@ hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, con
     static const bool no_q = std::getenv("RTX_HIP_NO_QNODES") != nullptr;
     const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : ((sv.bvh_flags & 8u) != 0u && !no_q ? 2 : 1);
     void (*kernel)(const SceneView *, const RowsView *, double *, Counters *, unsigned long long *, const float4 *, const LeafArrays,
-                   const MeshArrays, uint32_t *, uint32_t, uint32_t) = nullptr;
+                   const MeshArrays, uint32_t *, uint32_t, uint32_t, const MeshRaySource) = nullptr;
     const bool deep = spill_entries != 0u;
-    if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2> : trace_bvh_mesh_kernel<false, 2>;
-    else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1> : trace_bvh_mesh_kernel<false, 1>;
-    else kernel = deep ? trace_bvh_mesh_kernel<true, 0> : trace_bvh_mesh_kernel<false, 0>;
+    if (src) {                                   // (the hybrid exists for pure (x, y)-footprint trees)
+        if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2, true> : trace_bvh_mesh_kernel<false, 2, true>;
+        else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1, true> : trace_bvh_mesh_kernel<false, 1, true>;
+        else return hipErrorInvalidValue;
+    } else if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2, false> : trace_bvh_mesh_kernel<false, 2, false>;
+    else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1, false> : trace_bvh_mesh_kernel<false, 1, false>;
+    else kernel = deep ? trace_bvh_mesh_kernel<true, 0, false> : trace_bvh_mesh_kernel<false, 0, false>;
     const float4 *nodes = plain == 2 ? reinterpret_cast<const float4 *>(sv.bvh_qnodes) : reinterpret_cast<const float4 *>(sv.bvh_nodes);
+    MeshRaySource none{};
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
-                       nodes, la, ma, spill, spill_entries, thresh);
+                       nodes, la, ma, spill, spill_entries, thresh, src ? *src : none);
     return hipGetLastError();
+}
+
+hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                 double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
+                                 hipStream_t stream)
+{
+    return launch_mesh(d_sv, sv, d_rv, rv, samples, counters, work_counter, spill, n_cus, stream, nullptr);
+}
+
+hipError_t launch_trace_bvh_mesh_from_queue(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                            double *samples, Counters *counters, unsigned long long *head, const MeshRaySource &src,
+                                            uint32_t *spill, int n_cus, hipStream_t stream)
+{
+    return launch_mesh(d_sv, sv, d_rv, rv, samples, counters, head, spill, n_cus, stream, &src);
 }
 
 }  // namespace rtx

@@ -58,6 +58,20 @@ hipError_t launch_trace_bvh_mesh(const SceneView *d_sv, const SceneView &sv, con
                                  double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                  hipStream_t stream);
 
+// The same kernel fed from a queue of rays in flight instead of generating primary rays (the hybrid of rtx_wavefront.hip:
+// level 0 in the wavefront form, the deeper levels here).  src: structure-of-arrays state in queue order, the rays' indices
+// (ridx[k * ridx_stride]), the queue length on the device; the rays enter at path level 1.  head: a zeroed u64.
+struct MeshRaySource {
+    const double *pos[3], *dir[3], *res[3], *lig[3];
+    const uint32_t *left;                     // the triangle the ray has just left (index in tris[]), kNone = none
+    const uint32_t *ridx;
+    uint32_t ridx_stride;
+    const unsigned long long *count;
+};
+hipError_t launch_trace_bvh_mesh_from_queue(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
+                                            double *samples, Counters *counters, unsigned long long *head, const MeshRaySource &src,
+                                            uint32_t *spill, int n_cus, hipStream_t stream);
+
 // RTX_KERNEL_WAVEFRONT (rtx_wavefront.hip): the path of a pure (x, y)-footprint triangle tree as generate / walk / shade
 // kernels per bounce level, the ray state in HBM.  state_mem: wavefront_state_bytes(rv.n_rays, ...) bytes; spill:
 // wavefront_spill_bytes() bytes (may be 0).  Enqueues everything on `stream`; synchronises it only when max_bounces + 1

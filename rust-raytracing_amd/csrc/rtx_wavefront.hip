@@ -25,6 +25,7 @@
 #include "rtx_wavefront.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 namespace rtx {
@@ -538,8 +539,9 @@ uint32_t wavefront_spill_entries(const SceneView &sv)
 
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus)
 {
-    // one column per resident lane of the walk kernel
-    return (size_t)wavefront_spill_entries(sv) * (size_t)n_cus * kWfTraceWaves * kBvhThreads * sizeof(uint32_t);
+    // one column per resident lane of the walk kernel; the hybrid's megakernel stage uses the same buffer
+    const size_t own = (size_t)wavefront_spill_entries(sv) * (size_t)n_cus * kWfTraceWaves * kBvhThreads * sizeof(uint32_t);
+    return std::max(own, bvh_mesh_spill_bytes(sv, n_cus));
 }
 
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
@@ -585,7 +587,26 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
         hipLaunchKernelGGL(wf_shade_kernel, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, la);
         return hipGetLastError();
     };
-    return wf_run_levels(st, levels, stream, generate, level_fn);
+    // The hybrid: only level 0 in this form -- its packets are what pays (primary rays alone: C5 band 38 ms against the
+    // megakernel's 62, C3 30 against 68) -- and everything after the first hit in the regrouping megakernel, fed from level
+    // 1's queue: its per-lane walks run beside other waves' f64 phases, which the per-lane walk kernel here cannot offer
+    // (levels 1-10 of the C5 band: 55 ms here, ~33 ms there), and 4 kernels per launch instead of 23 suit small frames
+    // (C3 at 960x540x8: 15.2 ms against 21.1 all-wavefront and 25.4 megakernel; 480x270x8: 6.5 / 11.6 / 8.0).  All levels
+    // stay in this form only where that measured faster: a tree that fits the L2s and >= 2^24 rays in the launch (C3 at
+    // 1080p x 64 spp: 408 against 427 ms).  RTX_HIP_WF_PURE=1 / RTX_HIP_WF_HYBRID=1 force one or the other (tests, A/B runs).
+    const uint64_t tree_bytes = (uint64_t)sv.n_bvh_nodes * (sizeof(Bvh4Node) + sizeof(BvhQNode)) + (uint64_t)sv.n_tri_tree * 64u;
+    const bool all_levels = tree_bytes <= (32ull << 20) && n >= (1ull << 24);
+    const bool hybrid = (std::getenv("RTX_HIP_WF_HYBRID") || !all_levels) && !std::getenv("RTX_HIP_WF_PURE");
+    if (!hybrid) return wf_run_levels(st, levels, stream, generate, level_fn);
+    hipError_t e = wf_run_levels(st, 1u, stream, generate, level_fn);
+    if (e != hipSuccess || levels < 2u) return e;
+    MeshRaySource src;
+    for (int k = 0; k < 3; ++k) { src.pos[k] = st.ray[1].pos[k]; src.dir[k] = st.ray[1].dir[k]; src.res[k] = st.ray[1].res[k]; src.lig[k] = st.ray[1].lig[k]; }
+    src.left = st.ray[1].left;
+    src.ridx = &reinterpret_cast<const uint32_t *>(st.rec[1])[offsetof(WfRec, ridx) / sizeof(uint32_t)];
+    src.ridx_stride = sizeof(WfRec) / sizeof(uint32_t);
+    src.count = st.count + 1;
+    return launch_trace_bvh_mesh_from_queue(d_sv, sv, d_rv, rv, samples, counters, st.work + 1, src, spill, n_cus, stream);
 }
 
 }  // namespace rtx

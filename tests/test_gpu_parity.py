@@ -337,18 +337,26 @@ def test_mesh_kernel_paths(gpu, oracle):
     scene (f64 slab walk, inline flushes) and beyond any walk, a pure (x, y)-footprint tree (the PLAIN variant) and a
     joint tree with spheres and faces solved in other planes, needle / edge-on triangles the bounds can never certify.
     RTX_KERNEL_WAVEFRONT (the same step as a kernel of its own per bounce level, exact tests + ray_hit in a second kernel,
-    ray state in HBM) runs beside it: on the pure mesh it is the wavefront form (incl. more bounce levels than one
-    host-side chunk of 16, and sample batches), on the joint scenes it resolves to the regrouping kernel."""
+    ray state in HBM) runs beside it in both its modes -- every level in that form (incl. more bounce levels than one
+    host-side chunk of 16, and sample batches), and level 0 only with this kernel continuing from the level-1 queue; on
+    the joint scenes it resolves to the regrouping kernel."""
     import torch
     from rust_raytracing_amd import scenes
 
     def both(objs, cam, w=64, h=36, spp=2, **cfg):
         out = []
-        for kern in (gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_KERNEL_EXACT):
-            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
-            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
-            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-            hnd.close()
+        for kern, env in ((gpu.RTX_KERNEL_BVH_REGROUP, None), (gpu.RTX_KERNEL_WAVEFRONT, "RTX_HIP_WF_PURE"),
+                          (gpu.RTX_KERNEL_WAVEFRONT, "RTX_HIP_WF_HYBRID"), (gpu.RTX_KERNEL_EXACT, None)):
+            if env:
+                os.environ[env] = "1"              # every level in the wavefront form / the megakernel from level 1 on
+            try:
+                hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
+                buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+                st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+                hnd.close()
+            finally:
+                if env:
+                    del os.environ[env]
             out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
         for o in out[:-1]:
             assert np.array_equal(o[0], out[-1][0]) and o[1] == out[-1][1]
@@ -391,10 +399,12 @@ def test_mesh_kernel_paths(gpu, oracle):
 
 
 def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
-    """AUTO on a pure (x, y)-footprint mesh whose tree fits the L2s, with >= 2^22 rays: RTX_KERNEL_WAVEFRONT, whose level 0
-    walks each 8x8 tile of primary rays as one packet (wf_trace_packet_kernel).  Same bits as the regrouping megakernel,
-    as the wavefront form with per-lane walks at level 0 (RTX_HIP_NO_PACKETS), and the oracle on scattered pixels; below
-    the ray count AUTO stays with the megakernel.  A frame that does not divide into tiles and a row band are included."""
+    """AUTO on a pure (x, y)-footprint mesh with >= 2^20 rays: RTX_KERNEL_WAVEFRONT, whose level 0 walks each 8x8 tile of
+    primary rays as one packet (wf_trace_packet_kernel); the regrouping megakernel continues from the level-1 queue (the
+    default below 2^24 rays or for a tree beyond the L2s) or every level stays in the wavefront form (RTX_HIP_WF_PURE).  Same
+    bits as the megakernel alone, as the wavefront form with per-lane walks at level 0 (RTX_HIP_NO_PACKETS), and the
+    oracle on scattered pixels; below the ray count AUTO stays with the megakernel.  A frame that does not divide into
+    tiles and a row band are included."""
     import torch
     from rust_raytracing_amd import scenes
     objs = scenes.light_every(scenes.compact(scenes.random_triangles(30000, 8), k=0.06, x0=5.0))
@@ -420,15 +430,19 @@ def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
     assert st.kernel == gpu.RTX_KERNEL_WAVEFRONT
     mega, stm = render(gpu.RTX_KERNEL_BVH_REGROUP)
     assert np.array_equal(auto, mega) and st.segments == stm.segments
-    lanes, stl = render(gpu.RTX_KERNEL_WAVEFRONT, RTX_HIP_NO_PACKETS="1")
-    assert np.array_equal(auto, lanes) and stl.box_tests < st.box_tests        # (a packet tests the union of its rays' nodes)
+    pure, stp = render(gpu.RTX_KERNEL_WAVEFRONT, RTX_HIP_WF_PURE="1")
+    assert np.array_equal(auto, pure) and stp.segments == st.segments
+    for mode in ("RTX_HIP_WF_PURE", "RTX_HIP_WF_HYBRID"):
+        lanes, stl = render(gpu.RTX_KERNEL_WAVEFRONT, RTX_HIP_NO_PACKETS="1", **{mode: "1"})
+        assert np.array_equal(auto, lanes) and stl.box_tests < st.box_tests    # (a packet tests the union of its rays' nodes)
     xs, ys = _scattered_pixels(auto, 150, 40, seed=3)
     ref = oracle.render_pixels(oracle.make_scene(objs, DEFAULT_CAM, rays_per_pixel=spp, seed=42), w, h, xs, ys)
     assert max_abs_diff(auto[ys, xs], ref) <= ATOL
-    band, stb = render(gpu.RTX_KERNEL_WAVEFRONT, rb=3, rs=8, rows=len(range(3, h, 8)))
-    assert np.array_equal(band, auto[3::8])
-    small, sts = render(gpu.RTX_KERNEL_AUTO, rows=h // 2)                       # 2.1e6 rays: the megakernel
-    assert sts.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(small, auto[:h // 2])
+    for mode in ("RTX_HIP_WF_PURE", "RTX_HIP_WF_HYBRID"):
+        band, stb = render(gpu.RTX_KERNEL_WAVEFRONT, rb=3, rs=8, rows=len(range(3, h, 8)), **{mode: "1"})
+        assert np.array_equal(band, auto[3::8])
+    small, sts = render(gpu.RTX_KERNEL_AUTO, rows=h // 8)                       # 5.2e5 rays: the megakernel
+    assert sts.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(small, auto[:h // 8])
 
 
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
@@ -842,10 +856,11 @@ def _scattered_pixels(img, n_random, n_bright, seed):
 
 def test_c3_full_size_against_the_oracle(gpu, oracle):
     """BASELINE.json configs[2] on its own scene at its own size: 100k random triangles (scene seed 2), 1920x1080, AUTO
-    (= the regrouping BVH kernel).  (1) two renders are bit-identical, (2) segments within [rays, 11 rays], (3) 300+
+    (= the wavefront form: packets at level 0, the regrouping kernel from the level-1 queue).  (1) two renders are bit-identical, (2) segments within [rays, 11 rays], (3) 300+
     scattered pixels -- corners, edge columns, the brightest pixels, random ones -- equal the oracle's
     (rtxo_render_pixels: every triangle tested per segment, triangle.rs:108-127, scene.rs:243-251) within ATOL,
-    (4) the lock-step BVH kernel and the wavefront form (packets at level 0) produce the same frame bit for bit."""
+    (4) the lock-step BVH kernel, the regrouping kernel alone and the wavefront form at every level produce the same frame
+    bit for bit."""
     import torch
     from rust_raytracing_amd import scenes
     objs = scenes.random_triangles(100000, 2)
@@ -858,15 +873,20 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
     buf.zero_()
     hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
     assert np.array_equal(a, buf.cpu().numpy())
-    assert st.kernel == gpu.RTX_KERNEL_BVH_REGROUP
+    assert st.kernel == gpu.RTX_KERNEL_WAVEFRONT
     assert st.primary_rays == w * h * spp and w * h * spp <= st.segments <= 11 * w * h * spp
-    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_BVH))
-    buf.zero_()
-    st2 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-    assert np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
-    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT))       # (what AUTO runs from 2^22 rays on)
-    buf.zero_()
-    st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP):
+        hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=kern))
+        buf.zero_()
+        st2 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        assert st2.kernel == kern and np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
+    os.environ["RTX_HIP_WF_PURE"] = "1"                                          # every level in the wavefront form
+    try:
+        hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT))
+        buf.zero_()
+        st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+    finally:
+        del os.environ["RTX_HIP_WF_PURE"]
     assert st3.kernel == gpu.RTX_KERNEL_WAVEFRONT and np.array_equal(a, buf.cpu().numpy()) and st3.segments == st.segments
     hnd.close()
     xs, ys = _scattered_pixels(a, 200, 100, seed=11)
@@ -880,8 +900,10 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
 
 def test_c5_band_against_the_oracle(gpu, oracle):
     """BASELINE.json configs[4] on its own scene: 1M random triangles (scene seed 3, box x2), 3840x2160, the band rank 5
-    of 8 owns (270 interleaved rows), AUTO (= regrouping BVH kernel, deep tree -> the HBM stack-spill variant).
-    100+ scattered pixels of the band against the oracle, which tests all 10^6 triangles per segment."""
+    of 8 owns (270 interleaved rows), AUTO (at 1 spp just under 2^20 rays: the regrouping BVH kernel, deep tree -> the HBM
+    stack-spill variant) and the wavefront form AUTO takes from 2^20 rays on (packets at level 0 over a tree that exceeds
+    the L2s, the regrouping kernel from the level-1 queue), bit for bit.  100+ scattered pixels of the band against the
+    oracle, which tests all 10^6 triangles per segment."""
     import torch
     from rust_raytracing_amd import scenes, tiles
     objs = scenes.random_triangles(1000000, 3, box=2.0)
@@ -890,10 +912,14 @@ def test_c5_band_against_the_oracle(gpu, oracle):
     hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, seed=42), gpu.Camera(*scenes.CAMERA), objs).upload(0)
     band = tiles.alloc_band(h, w, world, "cuda:0")
     st = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
-    hnd.close()
     assert st.kernel == gpu.RTX_KERNEL_BVH_REGROUP and st.primary_rays == n * w * spp
     assert n * w * spp <= st.segments <= 11 * n * w * spp
     got = band[:n].cpu().numpy()
+    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT))
+    band.zero_()
+    stw = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+    hnd.close()
+    assert stw.kernel == gpu.RTX_KERNEL_WAVEFRONT and stw.segments == st.segments and np.array_equal(got, band[:n].cpu().numpy())
     xs, ks = _scattered_pixels(got, 64, 40, seed=12)            # ks = row index inside the band
     ys = (rb + ks.astype(np.int64) * rs).astype(np.uint32)
     osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=spp, seed=42)

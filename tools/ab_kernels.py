@@ -1,5 +1,5 @@
 """Kernel A against kernel B on a BASELINE config (same box, same process): time, rates, counters and bit equality of the frames.
-    tools/ab_kernels.py CONFIG SPP KERNEL_A KERNEL_B [band]      e.g.  C3 8 5 6   |   C5 4 5 6 band   (W / H override the frame size;
+    tools/ab_kernels.py CONFIG SPP KERNEL_A KERNEL_B [band]      e.g.  C3 8 5 6   |   C5 4 5 6 band   (W / H override the frame size, MAXB max_bounces;
     RTX_HIP_LIB selects another build of the library, see tools/build_variant.sh)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ rb, rs, n_rows = tiles.rows_for_rank(h, 0, world)
 dev = torch.device("cuda", 0)
 out = {}
 for k in (ka, kb):
-    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k), rtx.Camera(*scenes.CAMERA), objs).upload(0)
+    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k, max_bounces=int(os.environ.get("MAXB", 10))), rtx.Camera(*scenes.CAMERA), objs).upload(0)
     band = tiles.alloc_band(h, w, world, dev)
     hnd.render_rows(w, h, rb, rs, n_rows, band.data_ptr())
     torch.cuda.synchronize()
