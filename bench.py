@@ -67,14 +67,15 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                    "walk; trace_bvh_kernel when the tree holds triangles)",
                 5: "flat 4-wide BVH, regrouping schedule (trace_bvh_mesh_kernel: f32-only traversal step, exact f64 tests in the "
                    "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)",
-                6: "wavefront form (what AUTO runs for a pure mesh whose tree stays in L2): per bounce level a walk kernel (f32 only; "
-                   "level 0: wf_trace_packet_kernel, one wave-uniform walk per 8x8 tile of primary rays; deeper levels: wf_trace_kernel, "
-                   "one walk per lane, lanes refilled from the level's queue) and wf_shade_kernel (f64: exact tests, ray_hit), ray state "
-                   "in HBM; the roofline object covers the whole sequence of one launch, wf_trace_packet_kernel is ~55 % of it"}
+                6: "wavefront form (what AUTO runs for a pure mesh): level 0 = wf_generate_kernel, wf_trace_packet_kernel (f32 only, one "
+                   "wave-uniform walk per 8x8 tile of primary rays) and wf_shade_kernel (f64: exact tests, ray_hit), ray state in HBM; "
+                   "then trace_bvh_mesh_kernel continues from the level-1 queue (or, for an L2-resident tree with >= 2^24 rays per "
+                   "launch, wf_trace_kernel + wf_shade_kernel per bounce level); the roofline object covers the whole sequence of "
+                   "one launch, wf_trace_packet_kernel is ~55 % of it"}
 # substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
 KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
                  4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel", "trace_bvh_spheres_pool_kernel"),
-                 6: ("wf_trace_packet_kernel", "wf_trace_kernel", "wf_shade_kernel", "wf_generate_kernel",
+                 6: ("wf_trace_packet_kernel", "wf_trace_kernel", "wf_shade_kernel", "wf_generate_kernel", "trace_bvh_mesh_kernel",
                      "wf_trace_spheres_kernel", "wf_shade_spheres_kernel", "wf_generate_spheres_kernel")}
 PMC_LEG_RENDERS = 2                # renders of the workload a --pmc-leg child does (pmc_leg)
 # lane-op prices of the algorithmic counts (what the chosen algorithm needs at least; f64 instructions issue at half rate

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(
 // ---- closest_object's exact part, ray_hit, the next segment's set-up ---------------------------------------------------------
 __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
                                                                   const WfState st, uint32_t level, double *__restrict__ samples,
-                                                                  Counters *__restrict__ ctr, const LeafArrays la)
+                                                                  Counters *__restrict__ ctr, const LeafArrays la, uint32_t queue_only)
 {
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
@@ -478,29 +478,34 @@ __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(co
             if (done) {
                 store_sample(samples, rv, ridx, r.result);
             } else {
-                // the next segment: the reference's self-hit is tested here, exactly (rtx_bvh_mesh.hip), and bounds the walk
-                const RayX rn = make_rayx(r.pos, r.dir);
                 lt = h.kind == 2u ? h.local : kNone;
-                float bu = __builtin_inff();
-                if (lt != kNone) {
-                    double t;
-                    if (triangle_distance(la.tris[lt], rn, &t) && is_normal_positive(t)) { t0 = t; bu = round_up32(t); }
-                    exact += 1;
+                if (queue_only) {                  // the megakernel takes the ray from here and sets its next segment up itself
+                    w.ridx = ridx;
+                } else {
+                    // the next segment: the reference's self-hit is tested here, exactly (rtx_bvh_mesh.hip), and bounds the walk
+                    const RayX rn = make_rayx(r.pos, r.dir);
+                    float bu = __builtin_inff();
+                    if (lt != kNone) {
+                        double t;
+                        if (triangle_distance(la.tris[lt], rn, &t) && is_normal_positive(t)) { t0 = t; bu = round_up32(t); }
+                        exact += 1;
+                    }
+                    wf_make_rec(sv, r.pos, r.dir, rn.dirn, bu, ridx, w);
                 }
-                wf_make_rec(sv, r.pos, r.dir, rn.dirn, bu, ridx, w);
                 next = true;
             }
         }
         // the survivors move to the next level's queue: record and state at their new slot, unit stride across the block
         const unsigned long long slot = wf_append_block(&st.count[1], next, lds_append, it);
         if (next) {
-            recs_out[slot] = w;
+            if (queue_only) recs_out[slot].ridx = w.ridx;
+            else recs_out[slot] = w;
             rout.pos[0][slot] = r.pos.x; rout.pos[1][slot] = r.pos.y; rout.pos[2][slot] = r.pos.z;
             rout.dir[0][slot] = r.dir.x; rout.dir[1][slot] = r.dir.y; rout.dir[2][slot] = r.dir.z;
             rout.res[0][slot] = r.result.x; rout.res[1][slot] = r.result.y; rout.res[2][slot] = r.result.z;
             rout.lig[0][slot] = r.light.x; rout.lig[1][slot] = r.light.y; rout.lig[2][slot] = r.light.z;
             rout.left[slot] = lt;
-            rout.hit_t[slot] = t0;
+            if (!queue_only) rout.hit_t[slot] = t0;
         }
     }
 #pragma unroll
@@ -569,6 +574,16 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
         hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, s0);
         return hipGetLastError();
     };
+    // The hybrid: only level 0 in this form -- its packets are what pays (primary rays alone: C5 band 38 ms against the
+    // megakernel's 62, C3 30 against 68) -- and everything after the first hit in the regrouping megakernel, fed from level
+    // 1's queue: its per-lane walks run beside other waves' f64 phases, which the per-lane walk kernel here cannot offer
+    // (levels 1-10 of the C5 band: 55 ms here, ~33 ms there), and 4 kernels per launch instead of 23 suit small frames
+    // (C3 at 960x540x8: 15.2 ms against 21.1 all-wavefront and 25.4 megakernel; 480x270x8: 6.5 / 11.6 / 8.0).  All levels
+    // stay in this form only where that measured faster: a tree that fits the L2s and >= 2^24 rays in the launch (C3 at
+    // 1080p x 64 spp: 408 against 427 ms).  RTX_HIP_WF_PURE=1 / RTX_HIP_WF_HYBRID=1 force one or the other (tests, A/B runs).
+    const uint64_t tree_bytes = (uint64_t)sv.n_bvh_nodes * (sizeof(Bvh4Node) + sizeof(BvhQNode)) + (uint64_t)sv.n_tri_tree * 64u;
+    const bool all_levels = tree_bytes <= (32ull << 20) && n >= (1ull << 24);
+    const bool hybrid = (std::getenv("RTX_HIP_WF_HYBRID") || !all_levels) && !std::getenv("RTX_HIP_WF_PURE");
     // level 0 as packets: the ray queue in 8x8 tiles, a tree the wave-uniform stack can hold
     const bool packets = (sv.bvh_flags & 4u) != 0u && rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && !std::getenv("RTX_HIP_NO_PACKETS");
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kPkWaves);
@@ -584,19 +599,10 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(wf_shade_kernel, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, la);
+        hipLaunchKernelGGL(wf_shade_kernel, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, la,
+                           hybrid ? 1u : 0u);
         return hipGetLastError();
     };
-    // The hybrid: only level 0 in this form -- its packets are what pays (primary rays alone: C5 band 38 ms against the
-    // megakernel's 62, C3 30 against 68) -- and everything after the first hit in the regrouping megakernel, fed from level
-    // 1's queue: its per-lane walks run beside other waves' f64 phases, which the per-lane walk kernel here cannot offer
-    // (levels 1-10 of the C5 band: 55 ms here, ~33 ms there), and 4 kernels per launch instead of 23 suit small frames
-    // (C3 at 960x540x8: 15.2 ms against 21.1 all-wavefront and 25.4 megakernel; 480x270x8: 6.5 / 11.6 / 8.0).  All levels
-    // stay in this form only where that measured faster: a tree that fits the L2s and >= 2^24 rays in the launch (C3 at
-    // 1080p x 64 spp: 408 against 427 ms).  RTX_HIP_WF_PURE=1 / RTX_HIP_WF_HYBRID=1 force one or the other (tests, A/B runs).
-    const uint64_t tree_bytes = (uint64_t)sv.n_bvh_nodes * (sizeof(Bvh4Node) + sizeof(BvhQNode)) + (uint64_t)sv.n_tri_tree * 64u;
-    const bool all_levels = tree_bytes <= (32ull << 20) && n >= (1ull << 24);
-    const bool hybrid = (std::getenv("RTX_HIP_WF_HYBRID") || !all_levels) && !std::getenv("RTX_HIP_WF_PURE");
     if (!hybrid) return wf_run_levels(st, levels, stream, generate, level_fn);
     hipError_t e = wf_run_levels(st, 1u, stream, generate, level_fn);
     if (e != hipSuccess || levels < 2u) return e;
