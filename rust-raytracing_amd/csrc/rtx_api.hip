@@ -51,8 +51,10 @@ int usable_device_count()
 
 size_t scratch_cap_bytes()
 {
+    // per-render scratch of one handle: sized for a 288 GB part (24 GiB: a C2 frame of 64 spp -- 17.5 GB of sample records and
+    // queue -- and 59 M rays of the wavefront form run as one launch; fewer, larger launches measured 3-10 % faster)
     const char *e = std::getenv("RTX_HIP_SCRATCH_MB");
-    size_t mb = 8192;
+    size_t mb = 24576;
     if (e && *e) { long v = std::strtol(e, nullptr, 10); if (v > 0) mb = (size_t)v; }
     return mb << 20;
 }
@@ -693,7 +695,10 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     uint64_t batch = spp;
     {
         // bytes per ray of a batch: the 32-byte sample record (+ the wavefront kernels' state, ~270 B)
-        const uint64_t per_ray = 4 * sizeof(double) + (kernel == RTX_KERNEL_WAVEFRONT ? wavefront_state_bytes(1u << 20, 1) >> 20 : 0);
+        // (+ the survivors' queue of the sphere kernel's two-stage form, 100 B)
+        const bool sph2 = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0;
+        const uint64_t per_ray = 4 * sizeof(double) + (kernel == RTX_KERNEL_WAVEFRONT ? wavefront_state_bytes(1u << 20, 1) >> 20 : 0) +
+                                 (sph2 ? 12 * sizeof(double) + sizeof(uint32_t) : 0);
         const uint64_t fit = scratch_cap_bytes() / (per_sample64 * per_ray);
         const uint64_t fit32 = 0xFFFFFFF0ull / per_sample64;
         if (batch > fit) batch = fit ? fit : 1;
@@ -761,6 +766,12 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
+    // the sphere kernel's two-stage form from 2^20 rays per launch on (RTX_HIP_BVH_ONE_STAGE=1: one launch, for A/B runs)
+    const bool spheres_two_stage = spheres_kernel && batch * per_sample64 >= (1ull << 20) && h->cfg.max_bounces > 0 &&
+                                   !std::getenv("RTX_HIP_BVH_ONE_STAGE");
+    if (spheres_two_stage) {
+        if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
+    }
     if (kernel == RTX_KERNEL_WAVEFRONT) {
         const size_t need = wf_mesh ? wavefront_spill_bytes(h->sv, h->n_cus) : wavefront_spheres_spill_bytes(h->sv, h->n_cus);
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
@@ -823,7 +834,8 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             if (spheres_kernel)
                 RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
-                                                       reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+                                                       reinterpret_cast<uint32_t *>(h->state), h->n_cus,
+                                                       spheres_two_stage ? h->wf_state : nullptr, stream));
             else
                 RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));

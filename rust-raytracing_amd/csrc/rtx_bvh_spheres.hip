@@ -21,13 +21,30 @@ namespace rtx {
 constexpr int kSphWavesPerSimd = 4;          // = workgroups per CU (4 waves each)
 constexpr int kSphStack = 30;                // LDS stack entries per lane: (30 + 1 sink row + 2 * kSphQueue queue rows) KB per workgroup
 
-template <bool SPILL>
+// Two stages.  A wave's round lasts as long as its longest walk.  Primary rays (an 8x8 tile per wave: coherent, short
+// walks) and bounced rays (incoherent, long walks) in one wave make the primaries wait for the bounces: measured on C2,
+// the primary rays alone take 24.7 of the 89.5 ms although they are 47 % of the segments.  So the launch is split:
+//   MODE 1   primary rays only: every lane takes a fresh ray each round; a ray that survives its first hit goes to a
+//            queue (state structure-of-arrays by slot; a wave reserves 512 slots per atomic and marks what it leaves
+//            unused as dead)
+//   MODE 2   the same kernel fed from that queue: every lane carries a bounced ray, idle lanes take the next ones
+// MODE 0 is the single launch (small launches, A/B runs: RTX_HIP_BVH_ONE_STAGE=1).
+struct SphQueue {
+    double *pos[3], *dir[3], *res[3], *lig[3];
+    uint32_t *ridx;                           // kNone: a slot its wave reserved and did not use
+    unsigned long long *count;                // slots reserved by stage 1 = the length stage 2 walks
+    unsigned long long capacity;
+};
+constexpr uint32_t kSphQueueChunk = 512;
+
+template <bool SPILL, int MODE>
 __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spheres_kernel(const SceneView *__restrict__ svp,
                                                                              const RowsView *__restrict__ rvp,
                                                                              double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                              unsigned long long *__restrict__ work_counter,
                                                                              const float4 *__restrict__ nodes, const LeafArrays la,
-                                                                             uint32_t *__restrict__ spill, uint32_t spill_entries)
+                                                                             uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                                             const SphQueue sq)
 {
     constexpr int STACK = kSphStack;
     const SceneView &sv = *svp;
@@ -40,7 +57,9 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
     const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
 
+    const unsigned long long n_rays = MODE == 2 ? (*sq.count < sq.capacity ? *sq.count : sq.capacity) : rv.n_rays;
     unsigned long long wave_next = 0, wave_end = 0;      // this wave's share of the ray queue (wave-uniform)
+    unsigned long long out_next = 0, out_end = 0;        // MODE 1: this wave's reserved slots of the survivors' queue
     bool queue_empty = false;
     bool alive = false;
     RayState r;
@@ -57,21 +76,42 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                 base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
                        __builtin_amdgcn_readfirstlane((uint32_t)base);
                 wave_next = base;
-                wave_end = base + rv.grab < rv.n_rays ? base + rv.grab : rv.n_rays;
-                if (base >= rv.n_rays) { queue_empty = true; wave_next = wave_end = 0; }
+                wave_end = base + rv.grab < n_rays ? base + rv.grab : n_rays;
+                if (base >= n_rays) { queue_empty = true; wave_next = wave_end = 0; }
             }
             if (!alive && wave_next < wave_end) {
                 const unsigned long long my = wave_next + bvh_mbcnt(idle_mask);
                 bool valid = my < wave_end;
                 uint32_t pl = 0, smp = 0;
-                if (valid) {
-                    if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
-                    else ray_index_to_pixel(rv, my, pl, smp);
-                }
-                if (valid) {
-                    gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
-                    ridx = (uint32_t)my;                                          // (the host keeps rv.n_rays below 2^32)
-                    alive = true;
+                if constexpr (MODE == 2) {
+                    if (valid) {                           // a ray in flight, as stage 1 left it after its first hit
+                        ridx = sq.ridx[my];
+                        valid = ridx != kNone;
+                    }
+                    if (valid) {
+                        if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
+                        else ray_index_to_pixel(rv, ridx, pl, smp);
+                        const uint32_t k = pl / rv.width, x = pl - k * rv.width;
+                        const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                        r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
+                        r.bounce = 1u;
+                        r.draw = 8u;
+                        r.pos = mk(sq.pos[0][my], sq.pos[1][my], sq.pos[2][my]);
+                        r.dir = mk(sq.dir[0][my], sq.dir[1][my], sq.dir[2][my]);
+                        r.result = mk(sq.res[0][my], sq.res[1][my], sq.res[2][my]);
+                        r.light = mk(sq.lig[0][my], sq.lig[1][my], sq.lig[2][my]);
+                        alive = true;
+                    }
+                } else {
+                    if (valid) {
+                        if (rv.tiles_x != 0u) valid = ray_index_to_pixel_tiled(rv, my, pl, smp);
+                        else ray_index_to_pixel(rv, my, pl, smp);
+                    }
+                    if (valid) {
+                        gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
+                        ridx = (uint32_t)my;                                          // (the host keeps rv.n_rays below 2^32)
+                        alive = true;
+                    }
                 }
             }
             const unsigned long long taken = (unsigned long long)__popcll(idle_mask);
@@ -160,6 +200,40 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                 alive = false;
             }
         }
+        if constexpr (MODE == 1) {
+            // ---- the survivors of this round move to the queue of rays in flight; every lane is free again
+            const bool go = alive;
+            const unsigned long long m = __ballot(go);
+            const uint32_t n = (uint32_t)__popcll(m);
+            if (n != 0u) {
+                if (out_end - out_next < (unsigned long long)n) {
+                    // what is left of the wave's reservation does not take them: mark it unused, reserve the next chunk
+                    if (out_next + lane < out_end) sq.ridx[out_next + lane] = kNone;       // (fewer than 64 slots are left)
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(sq.count, (unsigned long long)kSphQueueChunk);
+                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                           __builtin_amdgcn_readfirstlane((uint32_t)base);
+                    out_next = base;
+                    out_end = base + kSphQueueChunk;
+                }
+                if (go) {
+                    const unsigned long long slot = out_next + bvh_mbcnt(m);
+                    if (slot < sq.capacity) {                  // (the host sizes the queue so that this always holds)
+                        sq.pos[0][slot] = r.pos.x; sq.pos[1][slot] = r.pos.y; sq.pos[2][slot] = r.pos.z;
+                        sq.dir[0][slot] = r.dir.x; sq.dir[1][slot] = r.dir.y; sq.dir[2][slot] = r.dir.z;
+                        sq.res[0][slot] = r.result.x; sq.res[1][slot] = r.result.y; sq.res[2][slot] = r.result.z;
+                        sq.lig[0][slot] = r.light.x; sq.lig[1][slot] = r.light.y; sq.lig[2][slot] = r.light.z;
+                        sq.ridx[slot] = ridx;
+                    }
+                }
+                out_next += n;
+            }
+            alive = false;
+        }
+    }
+    if constexpr (MODE == 1) {                    // the unused rest of the wave's last reservation
+        for (unsigned long long s = out_next + lane; s < out_end; s += 64ull)
+            if (s < sq.capacity) sq.ridx[s] = kNone;
     }
     // counters: segments, exact f64 shape tests, box tests + leaf filter tests (reported through filter_tests)
     unsigned long long filt = box_tests + leaf_filters;
@@ -190,9 +264,22 @@ size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus)
     return (size_t)bvh_spheres_spill_entries(sv) * (size_t)n_cus * kSphWavesPerSimd * kBvhThreads * sizeof(uint32_t);
 }
 
+// the survivors' queue of the two-stage form: 12 f64 + the ray index per slot, capacity = the launch's rays + what the waves'
+// reservations can leave unused, two u64 counters
+static uint64_t sph_queue_capacity(uint64_t n_rays, int n_cus)
+{
+    return n_rays + (uint64_t)n_cus * kSphWavesPerSimd * (kBvhThreads / 64) * (kSphQueueChunk + 64u) + kSphQueueChunk;
+}
+
+size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus)
+{
+    const uint64_t cap = sph_queue_capacity(n_rays, n_cus);
+    return (size_t)(cap * (12 * sizeof(double) + sizeof(uint32_t)) + 16 * 256);
+}
+
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    hipStream_t stream)
+                                    void *queue_mem, hipStream_t stream)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -202,9 +289,36 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
     la.sphere_f32 = sv.bvh_leaf_cr; la.sphere_prims = sv.bvh_prims; la.spheres = sv.spheres; la.sphere_ids = sv.sphere_id;
     la.tri_f32 = sv.tri_f32; la.tri_fidx = sv.tri_fidx; la.tris = sv.tris;
     const uint32_t spill_entries = spill ? bvh_spheres_spill_entries(sv) : 0u;
-    auto kernel = spill_entries != 0u ? trace_bvh_spheres_kernel<true> : trace_bvh_spheres_kernel<false>;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
-                       reinterpret_cast<const float4 *>(sv.bvh_nodes), la, spill, spill_entries);
+    const bool deep = spill_entries != 0u;
+    const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
+    SphQueue sq{};
+    if (!queue_mem || sv.max_bounces == 0) {     // one stage
+        auto kernel = deep ? trace_bvh_spheres_kernel<true, 0> : trace_bvh_spheres_kernel<false, 0>;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter, nodes, la,
+                           spill, spill_entries, sq);
+        return hipGetLastError();
+    }
+    // ---- two stages: carve the queue (every array on a 256-byte boundary), zero its two counters
+    const uint64_t capacity = sph_queue_capacity(rv.n_rays, n_cus);
+    char *p = static_cast<char *>(queue_mem);
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    unsigned long long *ctrs = reinterpret_cast<unsigned long long *>(take(2 * sizeof(unsigned long long)));
+    for (int k = 0; k < 3; ++k) sq.pos[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
+    for (int k = 0; k < 3; ++k) sq.dir[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
+    for (int k = 0; k < 3; ++k) sq.res[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
+    for (int k = 0; k < 3; ++k) sq.lig[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
+    sq.ridx = reinterpret_cast<uint32_t *>(take(capacity * sizeof(uint32_t)));
+    sq.count = ctrs;
+    sq.capacity = capacity;
+    hipError_t e = hipMemsetAsync(ctrs, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    auto k1 = deep ? trace_bvh_spheres_kernel<true, 1> : trace_bvh_spheres_kernel<false, 1>;
+    hipLaunchKernelGGL(k1, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter, nodes, la, spill,
+                       spill_entries, sq);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    auto k2 = deep ? trace_bvh_spheres_kernel<true, 2> : trace_bvh_spheres_kernel<false, 2>;
+    hipLaunchKernelGGL(k2, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, nodes, la, spill,
+                       spill_entries, sq);
     return hipGetLastError();
 }
 

@@ -32,9 +32,12 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
 // distance bounds, the exact tests after the walk, 5 waves per SIMD.  spill: bvh_spheres_spill_bytes() bytes (may be 0).
 uint32_t bvh_spheres_spill_entries(const SceneView &sv);
 size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
+// queue_mem: bvh_spheres_queue_bytes(rv.n_rays, n_cus) bytes for the two-stage form (primary rays in one launch, the rays that
+// survive their first hit in a second one fed from a queue), or null: one launch.
+size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    hipStream_t stream);
+                                    void *queue_mem, hipStream_t stream);
 
 // RTX_KERNEL_BVH_REGROUP for trees that hold spheres only (rtx_bvh_spheres_pool.hip): every lane owns a pool of rays, the
 // f64 phase serves all of them, the walk runs the lane's pending segments one after the other with the waiting lanes

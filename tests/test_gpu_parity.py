@@ -318,6 +318,29 @@ def test_spheres_kernel_paths(gpu, oracle):
     tiny["geom"][:, 0] = 10.0 + (tiny["geom"][:, 0] - 10.0) * 1e-3            # a thin slab the rays must cross
     both(tiny, scenes.CAMERA, w=128, h=72)
     both(c2, scenes.CAMERA, w=67, h=35, spp=3)                               # partial tiles (dead queue slots), odd sample count
+    # from 2^20 rays per launch on RTX_KERNEL_BVH runs in two stages (primary rays; then the rays that survived their first
+    # hit, from a queue whose unused reserved slots are marked dead): against one stage and the exhaustive kernel, with
+    # partial tiles, and with a scratch cap that cuts the frame into several launches
+    big = {}
+    for name, env in (("two", {}), ("one", {"RTX_HIP_BVH_ONE_STAGE": "1"}), ("two_batched", {"RTX_HIP_SCRATCH_MB": "200"})):
+        os.environ.update(env)
+        try:
+            hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_BVH, rays_per_pixel=2, seed=42).upload(0)
+            buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(1203, 997, 0, 1, 997, buf.data_ptr())
+            hnd.close()
+        finally:
+            for k in env:
+                del os.environ[k]
+        big[name] = (buf.cpu().numpy(), st.segments, st.trace_launches)
+    assert big["two"][2] == 1 and big["one"][2] == 1 and big["two_batched"][2] == 2
+    assert np.array_equal(big["two"][0], big["one"][0]) and big["two"][1] == big["one"][1]
+    assert np.array_equal(big["two"][0], big["two_batched"][0]) and big["two"][1] == big["two_batched"][1]
+    hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=2, seed=42).upload(0)
+    buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
+    ste = hnd.render_rows(1203, 997, 0, 1, 997, buf.data_ptr())
+    hnd.close()
+    assert np.array_equal(big["two"][0], buf.cpu().numpy()) and ste.segments == big["two"][1]
     bouncy = co.copy()
     bouncy["base_color"] = 0.97; bouncy["emission_color"] *= 0.05              # paths survive: more levels than one host-side chunk
     both(bouncy, scenes.CAMERA, max_bounces=40)
