@@ -323,7 +323,7 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     for (size_t k = 0; k < spheres.size() && spheres_finite; ++k)
         spheres_finite = sphere_box(scene->objects[sphere_id[k]].geom, sphere_boxes[k]);
     if (!spheres_finite || sphere_boxes.size() <= 4) sphere_boxes.clear();
-    static const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
+    const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
     BvhBuild &bvh = p.bvh;
     bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(), use_sah);
     Bvh4Build &bvh4 = p.bvh4;

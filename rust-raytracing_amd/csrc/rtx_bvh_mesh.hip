@@ -315,7 +315,7 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     const uint64_t cap = (uint64_t)n_cus * kMeshWaves;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
-    static const uint32_t thresh = [] {                         // tuning knob
+    const uint32_t thresh = [] {                         // tuning knob
         const char *e = std::getenv("RTX_HIP_BVH_THRESH");
         long v = e && *e ? std::strtol(e, nullptr, 10) : RTX_BVH_MESH_THRESH;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
@@ -327,7 +327,7 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     ma.sphere_cr = sv.bvh_leaf_cr; ma.sphere_prims = sv.bvh_prims; ma.tri_f32 = sv.tri_f32; ma.tri_geo = sv.tri_geo;
     const uint32_t spill_entries = spill ? bvh_mesh_spill_entries(sv) : 0u;
     // 0: a joint tree; 1: nothing but (x, y)-footprint triangles; 2: ... with the 64-byte nodes (RTX_HIP_NO_QNODES=1: A/B runs)
-    static const bool no_q = std::getenv("RTX_HIP_NO_QNODES") != nullptr;
+    const bool no_q = std::getenv("RTX_HIP_NO_QNODES") != nullptr;
     const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : ((sv.bvh_flags & 8u) != 0u && !no_q ? 2 : 1);
     void (*kernel)(const SceneView *, const RowsView *, double *, Counters *, unsigned long long *, const float4 *, const LeafArrays,
                    const MeshArrays, uint32_t *, uint32_t, uint32_t, const MeshRaySource) = nullptr;

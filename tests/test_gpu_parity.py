@@ -468,6 +468,42 @@ def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
     assert sts.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(small, auto[:h // 8])
 
 
+def test_ab_knobs_keep_the_bits(gpu):
+    """Every A/B environment knob of the library selects another schedule, node format or tree build -- never other bits.
+    Each one, on a pure mesh, a sphere scene and a joint scene, for the tree kernels, against the exhaustive f64 kernel:
+    RTX_HIP_BVH_CLASSIC (round 1's kernels), RTX_HIP_NO_QNODES (96-byte instead of 64-byte nodes), RTX_HIP_NO_TILES (ray
+    queue in rows instead of 8x8 tiles: also the wavefront form without packets), RTX_HIP_TRI_LEAF (1 / 4 triangles per
+    leaf), RTX_HIP_BVH_THRESH (regrouping threshold), RTX_HIP_BVH_MEDIAN (median splits instead of SAH)."""
+    import torch
+    from rust_raytracing_amd import scenes
+    mesh = scenes.light_every(scenes.compact(scenes.random_triangles(3000, 16), k=0.05, x0=5.0))
+    balls = scenes.light_every(scenes.compact(scenes.random_spheres(400, 15)))
+    joint = np.concatenate([balls[:200], mesh[:800], scenes.axis_aligned_mesh(40, x0=4.0, span=2.0)])
+    w, h, spp = 72, 40, 2
+
+    def render(objs, kern):
+        hnd = hip_scene(gpu, objs, cam=scenes.CAMERA, kernel=kern, rays_per_pixel=spp, seed=9).upload(0)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        hnd.close()
+        return buf.cpu().numpy(), st.segments
+
+    ref = {name: render(o, gpu.RTX_KERNEL_EXACT) for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint))}
+    knobs = [{}, {"RTX_HIP_BVH_CLASSIC": "1"}, {"RTX_HIP_NO_QNODES": "1"}, {"RTX_HIP_NO_TILES": "1"}, {"RTX_HIP_TRI_LEAF": "1"},
+             {"RTX_HIP_TRI_LEAF": "4"}, {"RTX_HIP_BVH_THRESH": "4"}, {"RTX_HIP_BVH_THRESH": "48"}, {"RTX_HIP_BVH_MEDIAN": "1"},
+             {"RTX_HIP_NO_QNODES": "1", "RTX_HIP_WF_PURE": "1"}, {"RTX_HIP_TRI_LEAF": "4", "RTX_HIP_WF_HYBRID": "1"}]
+    for env in knobs:
+        os.environ.update(env)
+        try:
+            for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint)):
+                for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT):
+                    img, segs = render(o, kern)
+                    assert np.array_equal(img, ref[name][0]) and segs == ref[name][1], (env, name, kern)
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
     """Spheres + triangles + a plane under one root; camera variants: inside the cloud looking along -z (rays nearly
     parallel to the footprints' unbounded axis), exactly axis-parallel directions (0 * inf in the slab test), and far
