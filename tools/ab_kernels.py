@@ -1,5 +1,5 @@
 """Kernel A against kernel B on a BASELINE config (same box, same process): time, rates, counters and bit equality of the frames.
-    tools/ab_kernels.py CONFIG SPP KERNEL_A KERNEL_B [band]      e.g.  C3 8 5 6   |   C5 4 5 6 band   (W / H override the frame size, MAXB max_bounces;
+    tools/ab_kernels.py CONFIG SPP KERNEL_A KERNEL_B [band]      e.g.  C3 8 5 6   |   C5 4 5 6 band   (W / H override the frame size, MAXB max_bounces, SCENE=axis:N[:mixed] the scene;
     RTX_HIP_LIB selects another build of the library, see tools/build_variant.sh)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,12 @@ name, spp, ka, kb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.arg
 world = 8 if len(sys.argv) > 5 and sys.argv[5] == "band" else 1
 cfg = bench.CONFIGS[name]
 objs = bench.make_objects(cfg)
+if os.environ.get("SCENE", "").startswith("axis"):                    # SCENE=axis:20000 -> 240k axis-aligned cube faces (+ SCENE=axis:20000:mixed: 2k spheres)
+    import numpy as np
+    parts = os.environ["SCENE"].split(":")
+    objs = scenes.axis_aligned_mesh(int(parts[1]), seed=9, span=80.0, x0=20.0)
+    if len(parts) > 2:
+        objs = np.concatenate([objs, scenes.random_spheres(2000, 13)])
 w, h = int(os.environ.get("W", cfg["w"])), int(os.environ.get("H", cfg["h"]))
 rb, rs, n_rows = tiles.rows_for_rank(h, 0, world)
 dev = torch.device("cuda", 0)
