@@ -56,8 +56,7 @@ enum {
     RTX_KERNEL_AUTO  = 0,  /* RTX_KERNEL_BVH when a tree was built at upload (more than 4 finite spheres and/or more than
                               4 triangles with a footprint) and at most 64 spheres/triangles stay outside it;
                               RTX_KERNEL_BVH_REGROUP instead when the tree holds a triangle mesh (>= 1024 triangles);
-                              RTX_KERNEL_WAVEFRONT when that mesh is nothing but (x, y)-footprint triangles and the
-                              call renders >= 2^20 rays;
+                              RTX_KERNEL_WAVEFRONT for such a mesh when the call renders >= 2^20 rays;
                               else RTX_KERNEL_MIXED.  All kernels produce the same bits, AUTO picks the fastest */
     RTX_KERNEL_EXACT = 1,  /* every shape test in f64, reference operation order */
     RTX_KERNEL_MIXED = 2,  /* f32 conservative LDS filter + exact f64 re-evaluation of candidates;
@@ -75,9 +74,9 @@ enum {
                               one wave-uniform walk per 8x8 tile of primary rays), the f64 exact tests + ray_hit in a
                               second kernel, the ray state structure-of-arrays in HBM between them.  For a mesh the
                               levels after the first run in RTX_KERNEL_BVH_REGROUP's kernel, fed from the level-1 queue,
-                              unless the tree fits the L2s and the launch has >= 2^24 rays.  For trees that hold nothing
-                              but (x, y)-footprint triangles (a mesh) or nothing but spheres, any other scene takes
-                              RTX_KERNEL_BVH_REGROUP; same bits */
+                              unless it is nothing but (x, y) footprints, fits the L2s and the launch has >= 2^24 rays.
+                              For trees that hold triangles (level 0 of a joint tree needs the tiled ray queue and a
+                              depth <= 42) or nothing but spheres, any other scene takes RTX_KERNEL_BVH_REGROUP; same bits */
 };
 
 /* One entry of Scene.objects (scene.rs:80), flattened: Object{shape, material} (object.rs:9-15)

@@ -668,11 +668,14 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         if (h->sv.n_bvh_nodes != 0 && outside_tree <= 64) {
             const bool mesh = (h->sv.bvh_flags & 2u) != 0u && h->sv.n_tri_tree >= 1024u;
             kernel = mesh ? RTX_KERNEL_BVH_REGROUP : RTX_KERNEL_BVH;
-            // a pure (x, y)-footprint mesh rendered with >= 2^20 rays: the wavefront form, whose level 0 walks a tile's
+            // a triangle mesh rendered with >= 2^20 rays: the wavefront form, whose level 0 walks a tile's
             // primary rays as one packet; the regrouping megakernel continues from its queue, or the deeper levels stay in
             // that form too (rtx_wavefront.hip).  Measured on C3 (100k triangles), wavefront vs megakernel: 1920x1080x8
             // 315 vs 166 Mrays/s, 960x540x8 272 vs 163, 480x270x8 160 vs 130; C5 band (1M triangles) 57 vs 44
-            if (mesh && (h->sv.bvh_flags & 4u) != 0u && (uint64_t)npix * spp >= (1ull << 20) && !std::getenv("RTX_HIP_NO_TILES"))
+            // (a joint tree -- spheres, faces solved in other planes -- takes the same form when its level 0 can walk as
+            // packets: 240k axis-aligned cube faces at 1080p x 8: 74.5 vs 46.7 Mrays/s, with 2k spheres 65.0 vs 43.2)
+            if (mesh && (uint64_t)npix * spp >= (1ull << 20) && wavefront_mesh_supported(h->sv, !std::getenv("RTX_HIP_NO_TILES")) &&
+                !std::getenv("RTX_HIP_NO_TILES"))
                 kernel = RTX_KERNEL_WAVEFRONT;
         } else {
             kernel = RTX_KERNEL_MIXED;
@@ -681,7 +684,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     // the wavefront form exists for pure (x, y)-footprint triangle trees and for trees that hold spheres only; any other
     // scene takes the regrouping kernel
-    const bool wf_mesh = (h->sv.bvh_flags & 4u) != 0u;
+    const bool wf_mesh = wavefront_mesh_supported(h->sv, !std::getenv("RTX_HIP_NO_TILES"));
     const bool wf_spheres = !wf_mesh && h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 3u) == 1u;
     if (kernel == RTX_KERNEL_WAVEFRONT && !wf_mesh && !wf_spheres) kernel = RTX_KERNEL_BVH_REGROUP;
     // the BVH kernels' ray queue runs over 8x8 pixel tiles (a wave's 64 rays = one tile); a sample then has

@@ -332,10 +332,10 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     void (*kernel)(const SceneView *, const RowsView *, double *, Counters *, unsigned long long *, const float4 *, const LeafArrays,
                    const MeshArrays, uint32_t *, uint32_t, uint32_t, const MeshRaySource) = nullptr;
     const bool deep = spill_entries != 0u;
-    if (src) {                                   // (the hybrid exists for pure (x, y)-footprint trees)
+    if (src) {
         if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2, true> : trace_bvh_mesh_kernel<false, 2, true>;
         else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1, true> : trace_bvh_mesh_kernel<false, 1, true>;
-        else return hipErrorInvalidValue;
+        else kernel = deep ? trace_bvh_mesh_kernel<true, 0, true> : trace_bvh_mesh_kernel<false, 0, true>;
     } else if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2, false> : trace_bvh_mesh_kernel<false, 2, false>;
     else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1, false> : trace_bvh_mesh_kernel<false, 1, false>;
     else kernel = deep ? trace_bvh_mesh_kernel<true, 0, false> : trace_bvh_mesh_kernel<false, 0, false>;

@@ -79,6 +79,7 @@ hipError_t launch_trace_bvh_mesh_from_queue(const SceneView *d_sv, const SceneVi
 // kernels per bounce level, the ray state in HBM.  state_mem: wavefront_state_bytes(rv.n_rays, ...) bytes; spill:
 // wavefront_spill_bytes() bytes (may be 0).  Enqueues everything on `stream`; synchronises it only when max_bounces + 1
 // exceeds 16 levels.
+bool wavefront_mesh_supported(const SceneView &sv, bool tiled);   // may RTX_KERNEL_WAVEFRONT take this tree (one that holds triangles)?
 size_t wavefront_state_bytes(uint64_t n_rays, uint32_t levels);
 uint32_t wavefront_levels(const SceneView &sv);
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus);

@@ -25,6 +25,7 @@
 #include "rtx_wavefront.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 
@@ -227,9 +228,13 @@ struct PkConst4 {
 __device__ __forceinline__ PkConst4 pk_const(const float4 *p) { return PkConst4{(const __attribute__((address_space(4))) PkF4 *)(uintptr_t)p}; }
 __device__ __forceinline__ uint32_t pk_bits(float f) { return __builtin_amdgcn_readfirstlane(__float_as_uint(f)); }
 
+// PLAIN 1: every node is a footprint node, every leaf a triangle leaf (C3, C5).  PLAIN 0: a joint tree -- 3-D nodes over
+// sphere boxes and the footprints of the other planes, the (x, y) footprint sub-tree behind links with kBvhFlatNode, sphere
+// leaves with bvh_traverse_spheres' bounds (cmax_ru: SceneView::sphere_cmax rounded up, for their error terms).
+template <int PLAIN>
 __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(const WfState st, Counters *__restrict__ ctr,
                                                                                 const float4 *__restrict__ nodes, const MeshArrays ma,
-                                                                                uint32_t root)
+                                                                                uint32_t root, float cmax_ru)
 {
     __shared__ uint32_t pk_stack[kBvhThreads >> 6][kPkStack];
     __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(
     grab = grab > 8ull ? 8ull : (grab < 1ull ? 1ull : grab);
     unsigned long long t_next = 0, t_end = 0;
     unsigned long long box_tests = 0, leaf_filters = 0;
-    const PkConst4 cnodes = pk_const(nodes), ctri = pk_const(ma.tri_f32), cgeo = pk_const(ma.tri_geo);
+    const PkConst4 cnodes = pk_const(nodes), ctri = pk_const(ma.tri_f32), cgeo = pk_const(ma.tri_geo), csph = pk_const(ma.sphere_cr);
 
     for (;;) {
         if (t_next >= t_end) {
@@ -272,17 +277,42 @@ __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(
         float best_up = walk ? w.best_up : -__builtin_inff();       // -inf: this lane enters nothing
         uint32_t qcnt = 0, nbox = 0, nleaf = 0;
         uint32_t sp = 0;
-        uint32_t node = __ballot(walk) != 0ull ? (root & ~kBvhFlatNode) : kNone;
+        uint32_t node = __ballot(walk) != 0ull ? (PLAIN ? (root & ~kBvhFlatNode) : root) : kNone;
+        SphereRay sr;                                               // (joint trees: sphere_ray_from's terms, from the record's f32 origin)
+        sr.px = w.px; sr.py = w.py; sr.pz = w.pz; sr.dx = w.dx; sr.dy = w.dy; sr.dz = w.dz;
+        sr.Kg = 0.0f; sr.c0 = __builtin_inff(); sr.K = 0.0f;
+        if constexpr (!PLAIN) {
+            const float pn = __builtin_amdgcn_sqrtf(__builtin_fmaf(w.px, w.px, __builtin_fmaf(w.py, w.py, w.pz * w.pz))) * (1.0f + 9.5367432e-7f);
+            const float M = (cmax_ru + pn) * (1.0f + 2.3841858e-7f);              // >= sphere_cmax + |p|
+            if (M < 1.0e14f && M > 1.0e-12f) {
+                const float u = 5.9604645e-8f;
+                sr.Kg = 128.0f * u * M * (1.0f + 4.76837158e-7f);
+                sr.c0 = 8192.0f * u * u * M * M * (1.0f + 9.5367432e-7f);
+                sr.K = 24.0f * u * M * (1.0f + 4.76837158e-7f);
+            } else {                                  // outside the range the bounds were derived for: every sphere of a visited leaf is a candidate
+                sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = 0.0f;
+            }
+        }
 
         while (node != kNone) {
-            // the footprint node's 96 bytes at a wave-uniform address: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
-            const PkConst4 np = cnodes + 8 * (size_t)node;
-            const float4 r0 = np[0], r1 = np[1], r2 = np[2], r3 = np[3], l4 = np[4], c4 = np[5];
-            const uint32_t lnk[4] = { pk_bits(l4.x), pk_bits(l4.y), pk_bits(l4.z), pk_bits(l4.w) };
-            const uint32_t cnt[4] = { pk_bits(c4.x), pk_bits(c4.y), pk_bits(c4.z), pk_bits(c4.w) };
+            // the node's bytes at a wave-uniform address.  A footprint node: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
+            // (96 bytes); a 3-D node of a joint tree: 4 x {lo.xyz, link}, 4 x {hi.xyz, count}
+            const PkConst4 np = cnodes + 8 * (size_t)(node & ~kBvhFlatNode);
+            uint32_t lnk[4], cnt[4];
             float tc[4];
-            tc[0] = rect_entry32(r0, q, best_up); tc[1] = rect_entry32(r1, q, best_up);
-            tc[2] = rect_entry32(r2, q, best_up); tc[3] = rect_entry32(r3, q, best_up);
+            if (PLAIN || (node & kBvhFlatNode)) {
+                const float4 r0 = np[0], r1 = np[1], r2 = np[2], r3 = np[3], l4 = np[4], c4 = np[5];
+                lnk[0] = pk_bits(l4.x); lnk[1] = pk_bits(l4.y); lnk[2] = pk_bits(l4.z); lnk[3] = pk_bits(l4.w);
+                cnt[0] = pk_bits(c4.x); cnt[1] = pk_bits(c4.y); cnt[2] = pk_bits(c4.z); cnt[3] = pk_bits(c4.w);
+                tc[0] = rect_entry32(r0, q, best_up); tc[1] = rect_entry32(r1, q, best_up);
+                tc[2] = rect_entry32(r2, q, best_up); tc[3] = rect_entry32(r3, q, best_up);
+            } else {
+                const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], b0 = np[4], b1 = np[5], b2 = np[6], b3 = np[7];
+                lnk[0] = pk_bits(a0.w); lnk[1] = pk_bits(a1.w); lnk[2] = pk_bits(a2.w); lnk[3] = pk_bits(a3.w);
+                cnt[0] = pk_bits(b0.w); cnt[1] = pk_bits(b1.w); cnt[2] = pk_bits(b2.w); cnt[3] = pk_bits(b3.w);
+                tc[0] = box_entry32(a0, b0, q, best_up); tc[1] = box_entry32(a1, b1, q, best_up);
+                tc[2] = box_entry32(a2, b2, q, best_up); tc[3] = box_entry32(a3, b3, q, best_up);
+            }
             if (best_up >= 0.0f) nbox += 4;
             uint32_t key[4], kl[4];                                // keys: the bits of a non-negative float order like the float
 #pragma unroll
@@ -290,16 +320,48 @@ __global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(
                 const bool in = tc[c] < __builtin_inff();
                 const unsigned long long hm = __ballot(in);
                 key[c] = 0x7F800000u;
-                kl[c] = lnk[c] & ~kBvhFlatNode;
+                kl[c] = PLAIN ? (lnk[c] & ~kBvhFlatNode) : lnk[c];
                 if (hm == 0ull || cnt[c] == 0xFFFFFFFFu) continue;
                 if (cnt[c] == 0u) {                                // interior: opened for the wave, ordered by its first entering lane
                     const int k = (int)__builtin_amdgcn_readlane(__float_as_uint(tc[c]), (int)(__ffsll((long long)hm) - 1));
                     key[c] = (uint32_t)(k < 0 ? 0 : k);            // (a slack can make the bound negative)
                     continue;
                 }
-                // a triangle leaf (uniform addresses): the lanes that enter it filter and bound its records
+                // a leaf (uniform addresses): the lanes that enter it filter and bound its records
                 const uint32_t first = lnk[c], n = cnt[c] & 0xFFFFu;
                 if (in) nleaf += n;
+                if (!PLAIN && (cnt[c] & kBvhTriLeaf) == 0u) {         // spheres: bvh_traverse_spheres' bounds (rtx_traverse.h)
+                    for (uint32_t j = 0; j < n; ++j) {
+                        const float4 rec = csph[first + j];                          // {c - centre, r}
+                        const uint32_t prim = ma.sphere_prims[first + j];
+                        if (!in) continue;
+                        const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+                        const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+                        const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
+                        const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+                        const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+                        const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+                        const float Dp = Dl + G;
+                        if (Dp >= 0.0f) {
+                            const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+                            const float Dm = Dl - G;
+                            const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+                            if (tlo <= best_up && !(thi < 0.0f)) {
+                                if (tlo > sr.K) best_up = fminf(best_up, thi);
+                                if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {
+                                    if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;
+                                    else { overflow = true; best_up = -__builtin_inff(); }
+                                }
+                                if (!overflow) {
+                                    lq[(size_t)qcnt * kBvhThreads + tid] = prim;
+                                    lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                                    qcnt += 1;
+                                }
+                            }
+                        }
+                    }
+                    continue;
+                }
                 for (uint32_t j = 0; j < n; ++j) {
                     const PkConst4 rp = ctri + 2 * (size_t)(first + j);
                     const float4 A = rp[0], B = rp[1];
@@ -427,25 +489,32 @@ __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(co
                     for (unsigned long long i = 0; i < nx; ++i) {
                         const uint2 x = st.extra[i];
                         if (x.x != (uint32_t)p) continue;
-                        const uint32_t tk = la.tri_fidx[x.y & ~kQueueTri];
                         double t;
-                        if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                        if (x.y & kQueueTri) {
+                            const uint32_t tk = la.tri_fidx[x.y & ~kQueueTri];
+                            if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                        } else if (sphere_distance(la.spheres[x.y], rx, &t)) hit_consider(h, t, la.sphere_ids[x.y], 0, x.y);
                         exact += 1;
                     }
                 }
 #pragma unroll 1
                 for (uint32_t e = 0; e < n; ++e) {
                     const uint32_t idx = e == 0 ? c.e[0] : e == 1 ? c.e[1] : e == 2 ? c.e[2] : e == 3 ? c.e[3] : e == 4 ? c.e[4] : c.e[5];
-                    const uint32_t tk = la.tri_fidx[idx & ~kQueueTri];
                     double t;
-                    if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                    if (idx & kQueueTri) {
+                        const uint32_t tk = la.tri_fidx[idx & ~kQueueTri];
+                        if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                    } else if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
                 }
                 exact += n;
             }
-            // the shapes outside the tree: every sphere (a pure mesh tree holds none), the planes, the triangles past n_tri_tree
-            for (uint32_t k = 0; k < sv.n_spheres; ++k) {
-                double t;
-                if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
+            // the shapes outside the tree: the spheres unless the tree holds them, the planes, the triangles past n_tri_tree
+            const bool sweep_spheres = !covered || (sv.bvh_flags & 1u) == 0u;
+            if (sweep_spheres) {
+                for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+                    double t;
+                    if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
+                }
             }
             for (uint32_t k = 0; k < sv.n_planes; ++k) {
                 double t;
@@ -457,7 +526,7 @@ __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(co
                 double t;
                 if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
             }
-            exact += sv.n_spheres + sv.n_planes + (sv.n_tri_filter - tri_sweep_from);
+            exact += (sweep_spheres ? sv.n_spheres : 0u) + sv.n_planes + (sv.n_tri_filter - tri_sweep_from);
 
             // ---- render_ray's match arm + ray_hit (scene.rs:232-239, 260-278)
             r.result = level == 0u ? mk(0.0, 0.0, 0.0) : mk(rin.res[0][p], rin.res[1][p], rin.res[2][p]);
@@ -542,6 +611,15 @@ uint32_t wavefront_spill_entries(const SceneView &sv)
     return need > (uint32_t)kWfStack ? need - (uint32_t)kWfStack : 0u;
 }
 
+// The wavefront form of a tree that holds triangles: any pure (x, y)-footprint tree; a joint tree (spheres, footprints of
+// other planes) when its level 0 can walk as packets -- the ray queue in tiles, a depth the wave-uniform stack holds.
+bool wavefront_mesh_supported(const SceneView &sv, bool tiled)
+{
+    if ((sv.bvh_flags & 2u) == 0u || sv.n_bvh_nodes == 0) return false;
+    if ((sv.bvh_flags & 4u) != 0u) return true;
+    return tiled && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack;
+}
+
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus)
 {
     // one column per resident lane of the walk kernel; the hybrid's megakernel stage uses the same buffer
@@ -582,14 +660,18 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     // stay in this form only where that measured faster: a tree that fits the L2s and >= 2^24 rays in the launch (C3 at
     // 1080p x 64 spp: 408 against 427 ms).  RTX_HIP_WF_PURE=1 / RTX_HIP_WF_HYBRID=1 force one or the other (tests, A/B runs).
     const uint64_t tree_bytes = (uint64_t)sv.n_bvh_nodes * (sizeof(Bvh4Node) + sizeof(BvhQNode)) + (uint64_t)sv.n_tri_tree * 64u;
-    const bool all_levels = tree_bytes <= (32ull << 20) && n >= (1ull << 24);
-    const bool hybrid = (std::getenv("RTX_HIP_WF_HYBRID") || !all_levels) && !std::getenv("RTX_HIP_WF_PURE");
+    const bool joint = (sv.bvh_flags & 4u) == 0u;      // spheres and / or footprints of other planes in the tree: packets + megakernel only
+    const bool all_levels = !joint && tree_bytes <= (32ull << 20) && n >= (1ull << 24);
+    const bool hybrid = joint || ((std::getenv("RTX_HIP_WF_HYBRID") || !all_levels) && !std::getenv("RTX_HIP_WF_PURE"));
     // level 0 as packets: the ray queue in 8x8 tiles, a tree the wave-uniform stack can hold
-    const bool packets = (sv.bvh_flags & 4u) != 0u && rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && !std::getenv("RTX_HIP_NO_PACKETS");
+    const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && (joint || !std::getenv("RTX_HIP_NO_PACKETS"));
+    if (joint && !packets) return hipErrorInvalidValue;      // (wavefront_mesh_supported() keeps the caller from asking)
+    const float cmax_ru = std::nextafterf((float)sv.sphere_cmax, INFINITY);
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kPkWaves);
     auto level_fn = [&](const WfState &sk, uint32_t level) {
         if (level == 0u && packets) {
-            hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root);
+            if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru);
+            else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru);
         } else if (qn) {
             if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);
             else hipLaunchKernelGGL((wf_trace_kernel<false, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);

@@ -437,7 +437,7 @@ def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
-            hnd = hip_scene(gpu, objs, kernel=kernel, rays_per_pixel=spp, seed=42).upload(0)
+            hnd = hip_scene(gpu, objs, kernel=kernel, rays_per_pixel=spp, seed=42).upload(0)       # (objs, spp: the enclosing scope's current values)
             buf = torch.zeros((rows, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, rb, rs, rows, buf.data_ptr())
             hnd.close()
@@ -466,6 +466,17 @@ def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
         assert np.array_equal(band, auto[3::8])
     small, sts = render(gpu.RTX_KERNEL_AUTO, rows=h // 8)                       # 5.2e5 rays: the megakernel
     assert sts.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(small, auto[:h // 8])
+    # a joint tree (spheres + faces solved in the other planes + (x, y) footprints under one root) takes the same form: its
+    # packets walk 3-D nodes, footprint nodes and sphere leaves; against the megakernel alone and the exhaustive kernel
+    objs = np.concatenate([scenes.compact(scenes.random_spheres(400, 3), k=0.06, x0=5.0), objs[:6000], scenes.axis_aligned_mesh(300, x0=4.0, span=2.0)])
+    stj = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*DEFAULT_CAM), objs))
+    assert stj["flags"] == 3 and stj["tri_other_footprints"] > 1000
+    spp = 8
+    autoj, st = render(gpu.RTX_KERNEL_AUTO, rows=h // 2)                        # 1.05e6 rays
+    assert st.kernel == gpu.RTX_KERNEL_WAVEFRONT
+    for kern in (gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_EXACT):
+        other, sto = render(kern, rows=h // 2)
+        assert np.array_equal(autoj, other) and sto.segments == st.segments
 
 
 def test_ab_knobs_keep_the_bits(gpu):
