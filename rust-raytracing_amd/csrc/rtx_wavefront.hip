@@ -216,7 +216,11 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
 // exact tests decide as always.  Pure (x, y)-footprint trees; the 96-byte footprint nodes (at a uniform address the two
 // extra requests are free and the rectangles need no decoding).
 constexpr int kPkStack = 128;                                      // wave-uniform stack entries (the host checks 3 * depth + 2 against it)
-constexpr int kPkWaves = 6;                                        // workgroups per CU
+constexpr int kPkWaves = 6;                                        // workgroups per CU (a joint tree's instance: kPkWavesJoint)
+#ifndef RTX_PK_WAVES_JOINT
+#define RTX_PK_WAVES_JOINT 6
+#endif
+constexpr int kPkWavesJoint = RTX_PK_WAVES_JOINT;
 
 // wave-uniform reads through the scalar cache: the constant address space makes the compiler select s_load for them
 typedef float PkF4 __attribute__((ext_vector_type(4)));
@@ -232,7 +236,7 @@ __device__ __forceinline__ uint32_t pk_bits(float f) { return __builtin_amdgcn_r
 // sphere boxes and the footprints of the other planes, the (x, y) footprint sub-tree behind links with kBvhFlatNode, sphere
 // leaves with bvh_traverse_spheres' bounds (cmax_ru: SceneView::sphere_cmax rounded up, for their error terms).
 template <int PLAIN>
-__global__ __launch_bounds__(kBvhThreads, kPkWaves) void wf_trace_packet_kernel(const WfState st, Counters *__restrict__ ctr,
+__global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void wf_trace_packet_kernel(const WfState st, Counters *__restrict__ ctr,
                                                                                 const float4 *__restrict__ nodes, const MeshArrays ma,
                                                                                 uint32_t root, float cmax_ru)
 {
@@ -667,7 +671,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && (joint || !std::getenv("RTX_HIP_NO_PACKETS"));
     if (joint && !packets) return hipErrorInvalidValue;      // (wavefront_mesh_supported() keeps the caller from asking)
     const float cmax_ru = std::nextafterf((float)sv.sphere_cmax, INFINITY);
-    const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kPkWaves);
+    const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * (joint ? kPkWavesJoint : kPkWaves));
     auto level_fn = [&](const WfState &sk, uint32_t level) {
         if (level == 0u && packets) {
             if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru);
