@@ -59,12 +59,18 @@ size_t scratch_cap_bytes()
     return mb << 20;
 }
 
-uint32_t tri_leaf_size()                 // triangles per BVH leaf; RTX_HIP_TRI_LEAF is a tuning knob (1..8)
+// Triangles per BVH leaf; RTX_HIP_TRI_LEAF is a tuning knob (1..6: a leaf must fit the walk's 6-entry candidate queue, or
+// every visit of it ends in the exhaustive sweep).  A tree of (x, y) footprints alone (`plain`: C3, C5) gets 4: measured with
+// the wavefront form (packets + the regrouping kernel from their queue), C3 1080p x 8 / C5 band x 4 in ms: 2: 53.2 / 72.6,
+// 3: 50.3 / 69.7, 4: 46.7 / 66.7, 5: 46.9 / 65.7, 6: 48.1 / 68.3 -- a packet tests a leaf's records for 64 rays at once, so
+// fewer, fuller leaves pay; the regrouping kernel alone (what small renders get) is level at 4 (99.6 / 96.2 against 99.2 /
+// 94.7) and loses 4 % at 5.  A joint tree keeps 2 (240k axis-aligned faces: 222 ms at 2, 242 at 4).
+uint32_t tri_leaf_size(bool plain)
 {
     const char *e = std::getenv("RTX_HIP_TRI_LEAF");
-    long v = 2;
+    long v = plain ? 4 : 2;
     if (e && *e) v = std::strtol(e, nullptr, 10);
-    return (uint32_t)(v < 1 ? 1 : (v > kBvhTriLeafMax ? kBvhTriLeafMax : v));
+    return (uint32_t)(v < 1 ? 1 : (v > (long)kQNodeLeafMax ? (long)kQNodeLeafMax : v));
 }
 
 }  // namespace
@@ -325,7 +331,8 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     if (!spheres_finite || sphere_boxes.size() <= 4) sphere_boxes.clear();
     const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
     BvhBuild &bvh = p.bvh;
-    bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(), use_sah);
+    const bool plain_tree = sphere_boxes.empty() && tri_boxes[0].empty() && tri_boxes[1].empty();   // (x, y) footprints alone (free axis 2)
+    bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(plain_tree), use_sah);
     Bvh4Build &bvh4 = p.bvh4;
     bvh4 = collapse_to_bvh4(bvh);
 
@@ -1124,10 +1131,10 @@ int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
             const BvhQNode &q = p.qnodes[k];
             const float lk[4] = { w.b[0].x, w.b[0].y, w.b[0].z, w.b[0].w }, ct[4] = { w.b[1].x, w.b[1].y, w.b[1].z, w.b[1].w };
             for (int c = 0; c < 4; ++c) {
-                const uint32_t count = bits(ct[c]), type = q.link[c] >> 30;
-                if ((count == 0xFFFFFFFFu) != (type == 3u)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised node: empty slot differs");
-                if (type == 3u) continue;
-                if ((q.link[c] & 0x3FFFFFFFu) != (bits(lk[c]) & ~kBvhFlatNode) || (type == 0u) != (count == 0u) ||
+                const uint32_t count = bits(ct[c]), type = q.link[c] >> kQNodeShift;
+                if ((count == 0xFFFFFFFFu) != (type == kQNodeEmpty)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised node: empty slot differs");
+                if (type == kQNodeEmpty) continue;
+                if ((q.link[c] & kQNodeIndexMask) != (bits(lk[c]) & ~kBvhFlatNode) || (type == 0u) != (count == 0u) ||
                     (type != 0u && type != (count & 0xFFFFu)))
                     return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: quantised node: link / count differs");
                 const double lx = (double)q.ox + (double)(q.qx[c] & 0xFFFFu) * q.sx, hx = (double)q.ox + (double)(q.qx[c] >> 16) * q.sx;

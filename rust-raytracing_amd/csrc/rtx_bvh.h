@@ -448,10 +448,11 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
 // The walk of a mesh is bound by how many address-divergent 16-byte requests the L1 serves: a footprint
 // node costs 6.  When the tree holds nothing but (x, y) footprints and no leaf has more than 2 records, every wide node
 // also exists in a 4-request form: the four child rectangles as 16-bit offsets from the node's own rectangle,
-//     {ox, oy, sx, sy}   {lo.x | hi.x << 16} x 4   {lo.y | hi.y << 16} x 4   {type << 30 | index} x 4
+//     {ox, oy, sx, sy}   {lo.x | hi.x << 16} x 4   {lo.y | hi.y << 16} x 4   {type << 29 | index} x 4
 // child plane = ox + q * sx with sx a power of two (so q * sx is exact), lo rounded down, hi rounded up: the decoded
 // rectangle contains the f32 rectangle of the 128-byte node, which already carries the padding the f32 slab test needs;
-// type 0 = interior (index = wide node), 1 / 2 = triangle leaf with that many records (index = first record), 3 = empty.
+// type 0 = interior (index = wide node), 1..6 = triangle leaf with that many records (index = first record), 7 = empty.
+constexpr uint32_t kQNodeShift = 29, kQNodeIndexMask = (1u << 29) - 1u, kQNodeEmpty = 7u, kQNodeLeafMax = 6u;
 struct BvhQNode {
     float ox, oy, sx, sy;
     uint32_t qx[4], qy[4], link[4];
@@ -485,7 +486,7 @@ inline bool build_qnodes(const Bvh4Build &b4, std::vector<BvhQNode> &out)
         }
         q.ox = (float)o[0]; q.oy = (float)o[1]; q.sx = (float)sc[0]; q.sy = (float)sc[1];
         for (int c = 0; c < 4; ++c) {
-            if (ct[c] == 0xFFFFFFFFu) { q.qx[c] = 0x0000FFFFu; q.qy[c] = 0x0000FFFFu; q.link[c] = 3u << 30; continue; }
+            if (ct[c] == 0xFFFFFFFFu) { q.qx[c] = 0x0000FFFFu; q.qy[c] = 0x0000FFFFu; q.link[c] = kQNodeEmpty << kQNodeShift; continue; }
             const double l0 = std::floor(((double)w.a[c].x - o[0]) / sc[0]), h0 = std::ceil(((double)w.a[c].z - o[0]) / sc[0]);
             const double l1 = std::floor(((double)w.a[c].y - o[1]) / sc[1]), h1 = std::ceil(((double)w.a[c].w - o[1]) / sc[1]);
             if (l0 < 0 || l1 < 0 || h0 > 65535 || h1 > 65535) return false;
@@ -493,12 +494,12 @@ inline bool build_qnodes(const Bvh4Build &b4, std::vector<BvhQNode> &out)
             q.qy[c] = (uint32_t)l1 | ((uint32_t)h1 << 16);
             uint32_t type;
             if (ct[c] == 0u) type = 0u;
-            else if ((ct[c] & kBvhTriLeaf) && (ct[c] & 0xFFFFu) >= 1u && (ct[c] & 0xFFFFu) <= 2u) type = ct[c] & 0xFFFFu;
+            else if ((ct[c] & kBvhTriLeaf) && (ct[c] & 0xFFFFu) >= 1u && (ct[c] & 0xFFFFu) <= kQNodeLeafMax) type = ct[c] & 0xFFFFu;
             else return false;                                              // a sphere leaf or a bigger leaf: no 64-byte form
             const uint32_t idx = lk[c] & ~kBvhFlatNode;
-            if (idx >= (1u << 30)) return false;
+            if (idx > kQNodeIndexMask) return false;
             if (type == 0u && !(lk[c] & kBvhFlatNode)) return false;        // an interior child that is not a footprint node
-            q.link[c] = (type << 30) | idx;
+            q.link[c] = (type << kQNodeShift) | idx;
         }
         out.push_back(q);
     }

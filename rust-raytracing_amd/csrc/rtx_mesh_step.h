@@ -163,9 +163,9 @@ __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, cons
         const uint32_t w[4] = { __float_as_uint(nd[3].x), __float_as_uint(nd[3].y), __float_as_uint(nd[3].z), __float_as_uint(nd[3].w) };
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const uint32_t type = w[c] >> 30;
-            lnk[c] = w[c] & 0x3FFFFFFFu;
-            cnt[c] = type == 0u ? 0u : (type == 3u ? 0xFFFFFFFFu : (type | kBvhTriLeaf));
+            const uint32_t type = w[c] >> kQNodeShift;
+            lnk[c] = w[c] & kQNodeIndexMask;
+            cnt[c] = type == 0u ? 0u : (type == kQNodeEmpty ? 0xFFFFFFFFu : (type | kBvhTriLeaf));
         }
     } else if (PLAIN || (cur & kBvhFlatNode)) {
         lnk[0] = __float_as_uint(nd[4].x); lnk[1] = __float_as_uint(nd[4].y); lnk[2] = __float_as_uint(nd[4].z); lnk[3] = __float_as_uint(nd[4].w);

@@ -483,8 +483,8 @@ def test_ab_knobs_keep_the_bits(gpu):
     """Every A/B environment knob of the library selects another schedule, node format or tree build -- never other bits.
     Each one, on a pure mesh, a sphere scene and a joint scene, for the tree kernels, against the exhaustive f64 kernel:
     RTX_HIP_BVH_CLASSIC (round 1's kernels), RTX_HIP_NO_QNODES (96-byte instead of 64-byte nodes), RTX_HIP_NO_TILES (ray
-    queue in rows instead of 8x8 tiles: also the wavefront form without packets), RTX_HIP_TRI_LEAF (1 / 4 triangles per
-    leaf), RTX_HIP_BVH_THRESH (regrouping threshold), RTX_HIP_BVH_MEDIAN (median splits instead of SAH)."""
+    queue in rows instead of 8x8 tiles: also the wavefront form without packets), RTX_HIP_TRI_LEAF (1 / 2 / 6 triangles per
+    leaf instead of 4; larger values are clamped to 6), RTX_HIP_BVH_THRESH (regrouping threshold), RTX_HIP_BVH_MEDIAN (median splits instead of SAH)."""
     import torch
     from rust_raytracing_amd import scenes
     mesh = scenes.light_every(scenes.compact(scenes.random_triangles(3000, 16), k=0.05, x0=5.0))
@@ -501,8 +501,8 @@ def test_ab_knobs_keep_the_bits(gpu):
 
     ref = {name: render(o, gpu.RTX_KERNEL_EXACT) for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint))}
     knobs = [{}, {"RTX_HIP_BVH_CLASSIC": "1"}, {"RTX_HIP_NO_QNODES": "1"}, {"RTX_HIP_NO_TILES": "1"}, {"RTX_HIP_TRI_LEAF": "1"},
-             {"RTX_HIP_TRI_LEAF": "4"}, {"RTX_HIP_BVH_THRESH": "4"}, {"RTX_HIP_BVH_THRESH": "48"}, {"RTX_HIP_BVH_MEDIAN": "1"},
-             {"RTX_HIP_NO_QNODES": "1", "RTX_HIP_WF_PURE": "1"}, {"RTX_HIP_TRI_LEAF": "4", "RTX_HIP_WF_HYBRID": "1"}]
+             {"RTX_HIP_TRI_LEAF": "2"}, {"RTX_HIP_TRI_LEAF": "6"}, {"RTX_HIP_TRI_LEAF": "8"}, {"RTX_HIP_BVH_THRESH": "4"}, {"RTX_HIP_BVH_THRESH": "48"}, {"RTX_HIP_BVH_MEDIAN": "1"},
+             {"RTX_HIP_NO_QNODES": "1", "RTX_HIP_WF_PURE": "1"}, {"RTX_HIP_TRI_LEAF": "6", "RTX_HIP_WF_HYBRID": "1"}]
     for env in knobs:
         os.environ.update(env)
         try:
