@@ -52,6 +52,7 @@ static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 
 constexpr uint32_t kBvhTriLeaf = 0x10000u;  // flag in a leaf's count: the entries are triangle filter records
 constexpr int kBvhLeafSize = 1;            // spheres per leaf; measured on C2 at 16 spp: leaf 1/2/4/8/16 = 1123/999/919/840/668 Mrays/s
+                                           // (round 1); with round 2's two-stage kernel at 64 spp: leaf 1/2/3 = 1616/1544/1484
                                            // (storing the sphere's filter record in place of the leaf box was slower: 1057)
 constexpr int kBvhTriLeafMax = 8;          // upper bound of triangles per leaf (the build's leaf size is a parameter)
 
