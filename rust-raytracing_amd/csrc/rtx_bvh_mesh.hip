@@ -315,9 +315,14 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     const uint64_t cap = (uint64_t)n_cus * kMeshWaves;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
-    const uint32_t thresh = [] {                         // tuning knob
+    // lanes that wait for the f64 phase before it runs (tuning knob).  Fed from a queue of bounced rays the kernel holds no
+    // primary rays, whose long walks made early phases pay; measured there (C3 / C5 band, the whole wavefront launch in ms):
+    // 8: 52.5 / 70.0, 16: 46.9 / 66.7, 24: 44.5 / 66.0, 32: 43.2 / 64.7, 40: 43.1 / 65.2, 48: 43.8 / 69.4, 64: 59.0 / 135;
+    // generating its own rays 16 stays (C5 band alone: 96 ms at 16, 108 at 32), and so it does for a joint tree (240k axis-aligned
+    // faces from the queue: 222 ms at 16, 233 at 32)
+    const uint32_t thresh = [&] {
         const char *e = std::getenv("RTX_HIP_BVH_THRESH");
-        long v = e && *e ? std::strtol(e, nullptr, 10) : RTX_BVH_MESH_THRESH;
+        long v = e && *e ? std::strtol(e, nullptr, 10) : (src && (sv.bvh_flags & 4u) != 0u ? 2 * RTX_BVH_MESH_THRESH : RTX_BVH_MESH_THRESH);
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     LeafArrays la;
