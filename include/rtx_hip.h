@@ -73,8 +73,7 @@ enum {
     RTX_KERNEL_WAVEFRONT = 6   /* the same tree walked by a kernel of its own per bounce level (f32 only; level 0 of a mesh:
                               one wave-uniform walk per 8x8 tile of primary rays), the f64 exact tests + ray_hit in a
                               second kernel, the ray state structure-of-arrays in HBM between them.  For a mesh the
-                              levels after the first run in RTX_KERNEL_BVH_REGROUP's kernel, fed from the level-1 queue,
-                              unless it is nothing but (x, y) footprints, fits the L2s and the launch has >= 2^24 rays.
+                              levels after the first run in RTX_KERNEL_BVH_REGROUP's kernel, fed from the level-1 queue.
                               For trees that hold triangles (level 0 of a joint tree needs the tiled ray queue and a
                               depth <= 42) or nothing but spheres, any other scene takes RTX_KERNEL_BVH_REGROUP; same bits */
 };

@@ -656,17 +656,15 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
         hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, s0);
         return hipGetLastError();
     };
-    // The hybrid: only level 0 in this form -- its packets are what pays (primary rays alone: C5 band 38 ms against the
-    // megakernel's 62, C3 30 against 68) -- and everything after the first hit in the regrouping megakernel, fed from level
-    // 1's queue: its per-lane walks run beside other waves' f64 phases, which the per-lane walk kernel here cannot offer
-    // (levels 1-10 of the C5 band: 55 ms here, ~33 ms there), and 4 kernels per launch instead of 23 suit small frames
-    // (C3 at 960x540x8: 15.2 ms against 21.1 all-wavefront and 25.4 megakernel; 480x270x8: 6.5 / 11.6 / 8.0).  All levels
-    // stay in this form only where that measured faster: a tree that fits the L2s and >= 2^24 rays in the launch (C3 at
-    // 1080p x 64 spp: 408 against 427 ms).  RTX_HIP_WF_PURE=1 / RTX_HIP_WF_HYBRID=1 force one or the other (tests, A/B runs).
-    const uint64_t tree_bytes = (uint64_t)sv.n_bvh_nodes * (sizeof(Bvh4Node) + sizeof(BvhQNode)) + (uint64_t)sv.n_tri_tree * 64u;
+    // The hybrid (the default): only level 0 in this form -- its packets are what pays (primary rays alone: C5 band 38 ms
+    // against the megakernel's 62, C3 30 against 68) -- and everything after the first hit in the regrouping megakernel, fed
+    // from level 1's queue: its per-lane walks run beside other waves' f64 phases, which the per-lane walk kernel here cannot
+    // offer (levels 1-10 of the C5 band: 55 ms here, ~33 ms there), and 4 kernels per launch instead of 23 suit small frames
+    // (C3 at 960x540x8: 15.2 ms against 21.1 all-wavefront and 25.4 megakernel; 480x270x8: 6.5 / 11.6 / 8.0).  With 4 triangles
+    // per leaf and the queue-fed stage's own regrouping threshold it is level with the all-wavefront form even on C3 at
+    // 1080p x 64 spp (322.6 against 322.9 ms), so that form runs only on request: RTX_HIP_WF_PURE=1 (tests, A/B runs).
     const bool joint = (sv.bvh_flags & 4u) == 0u;      // spheres and / or footprints of other planes in the tree: packets + megakernel only
-    const bool all_levels = !joint && tree_bytes <= (32ull << 20) && n >= (1ull << 24);
-    const bool hybrid = joint || ((std::getenv("RTX_HIP_WF_HYBRID") || !all_levels) && !std::getenv("RTX_HIP_WF_PURE"));
+    const bool hybrid = joint || !std::getenv("RTX_HIP_WF_PURE");
     // level 0 as packets: the ray queue in 8x8 tiles, a tree the wave-uniform stack can hold
     const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && (joint || !std::getenv("RTX_HIP_NO_PACKETS"));
     if (joint && !packets) return hipErrorInvalidValue;      // (wavefront_mesh_supported() keeps the caller from asking)
