@@ -216,9 +216,12 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
 // exact tests decide as always.  Pure (x, y)-footprint trees; the 96-byte footprint nodes (at a uniform address the two
 // extra requests are free and the rectangles need no decoding).
 constexpr int kPkStack = 128;                                      // wave-uniform stack entries (the host checks 3 * depth + 2 against it)
-constexpr int kPkWaves = 6;                                        // workgroups per CU (a joint tree's instance: kPkWavesJoint)
+#ifndef RTX_PK_WAVES
+#define RTX_PK_WAVES 7
+#endif
+constexpr int kPkWaves = RTX_PK_WAVES;                             // workgroups per CU (a joint tree's instance: kPkWavesJoint)
 #ifndef RTX_PK_WAVES_JOINT
-#define RTX_PK_WAVES_JOINT 6
+#define RTX_PK_WAVES_JOINT 7
 #endif
 constexpr int kPkWavesJoint = RTX_PK_WAVES_JOINT;
 
