@@ -64,7 +64,8 @@ CONFIGS = {
 KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 filter sweep + exact f64 (trace_mixed_kernel)",
                 3: "trace_mixed_kernel + verify",
                 4: "flat 4-wide BVH, lock-step waves (trace_bvh_spheres_kernel: f32-only traversal loop, exact f64 tests after the "
-                   "walk; trace_bvh_kernel when the tree holds triangles)",
+                   "walk; from 2^20 rays per launch on in two stages -- primary rays, then the rays that survived their first hit, "
+                   "from a queue -- both counted into the launch; trace_bvh_kernel when the tree holds triangles)",
                 5: "flat 4-wide BVH, regrouping schedule (trace_bvh_mesh_kernel: f32-only traversal step, exact f64 tests in the "
                    "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)",
                 6: "wavefront form (what AUTO runs for a pure mesh): level 0 = wf_generate_kernel, wf_trace_packet_kernel (f32 only, one "
