@@ -539,7 +539,7 @@ def test_fuzz_random_scenes_all_kernels_match_oracle(gpu, oracle):
         cfg = dict(rays_per_pixel=2, seed=it, max_bounces=int(rng.choice([0, 3, 10])))
         ref = oracle_render(oracle, objs, 20, 12, cam=cam, **cfg)
         nonblack += int(np.nanmax(ref) > 0) if ref.size else 0
-        for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP):
+        for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_MIXED, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT):
             got = hip_render(gpu, objs, 20, 12, cam=cam, kernel=kern, **cfg)
             assert max_abs_diff(got, ref) <= ATOL, (it, kern, len(objs))
     assert nonblack >= 75
