@@ -60,15 +60,16 @@ size_t scratch_cap_bytes()
 }
 
 // Triangles per BVH leaf; RTX_HIP_TRI_LEAF is a tuning knob (1..6: a leaf must fit the walk's 6-entry candidate queue, or
-// every visit of it ends in the exhaustive sweep).  A tree of (x, y) footprints alone (`plain`: C3, C5) gets 4: measured with
-// the wavefront form (packets + the regrouping kernel from their queue), C3 1080p x 8 / C5 band x 4 in ms: 2: 53.2 / 72.6,
-// 3: 50.3 / 69.7, 4: 46.7 / 66.7, 5: 46.9 / 65.7, 6: 48.1 / 68.3 -- a packet tests a leaf's records for 64 rays at once, so
-// fewer, fuller leaves pay; the regrouping kernel alone (what small renders get) is level at 4 (99.6 / 96.2 against 99.2 /
-// 94.7) and loses 4 % at 5.  A joint tree keeps 2 (240k axis-aligned faces: 222 ms at 2, 242 at 4).
+// every visit of it ends in the exhaustive sweep).  A tree of (x, y) footprints alone (`plain`: C3, C5) gets 5: a packet tests
+// a leaf's records for 64 rays at once and the regrouping kernel's leaf half reads one leaf per lane per iteration
+// (rtx_mesh_step.h), so fewer, fuller leaves pay.  Measured, C3 1080p x 8 / C5 band x 4 in ms, the wavefront form | the
+// regrouping kernel alone:  3: 41.7 / 59.5 | 79.8 / 75.2,  4: 39.5 / 56.4 | 76.5 / 72.3,  5: 38.0 / 55.2 | 77.4 / 72.1,
+// 6: 38.6 / 56.6 | 78.9 / 74.0  (2, before the step was split: 53.2 / 72.6 | 99.2 / 94.7).  A joint tree keeps 2 (240k axis-aligned
+// faces: 222 ms at 2, 242 at 4).
 uint32_t tri_leaf_size(bool plain)
 {
     const char *e = std::getenv("RTX_HIP_TRI_LEAF");
-    long v = plain ? 4 : 2;
+    long v = plain ? 5 : 2;
     if (e && *e) v = std::strtol(e, nullptr, 10);
     return (uint32_t)(v < 1 ? 1 : (v > (long)kQNodeLeafMax ? (long)kQNodeLeafMax : v));
 }

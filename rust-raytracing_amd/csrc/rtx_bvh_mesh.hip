@@ -33,6 +33,10 @@ namespace rtx {
 #define RTX_MESH_WAVES 4
 #endif
 constexpr uint32_t kMeshWaves = RTX_MESH_WAVES;   // waves per SIMD (= workgroups per CU)
+#ifndef RTX_MESH_SPLIT
+#define RTX_MESH_SPLIT 1
+#endif
+
 constexpr int kMeshStack = (RTX_MESH_WAVES <= 4 ? 39 : 160 / RTX_MESH_WAVES) - 1 - 2 * kMeshQueue;   // LDS stack entries per lane: (entries + 1 sink row + 2 * kMeshQueue) KB per workgroup
 // QUEUE: the rays are not generated here but taken from `src`, a queue of rays in flight at path level 1 (the hybrid of
 // rtx_wavefront.hip: the primary rays of a mesh whose tree exceeds the L2s walk as packets there, and everything after the
@@ -70,6 +74,9 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
     TriFilterParams tpar;
     float best_up = 0.f;
     uint32_t node = kNone, sp = 0, qcnt = 0, nbox = 0, nleaf = 0, resume = 0, resume_node = 0;
+    constexpr bool kSplit = RTX_MESH_SPLIT != 0 && PLAIN == 2;      // the step in two halves (rtx_mesh_step.h)
+    MeshPending pend;
+    pend.p0 = pend.p1 = pend.p2 = pend.p3 = 0u; pend.n = 0u;
     bool overflow = false, tree_used = false;
     uint32_t ridx = 0;
     uint32_t left_tri = kNone;               // the triangle (index in tris[]) the ray has just bounced off, if any
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
                 tri_filter_from_ray(sv, r.pos, r.dir, tpar);
                 make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
                 node = sv.bvh_root;              // wide node 0 (flagged when it is a footprint node)
+                if constexpr (kSplit) { node &= ~kBvhFlatNode; pend.n = 0u; }
                 state = S_TRAV;
             } else {
                 if (omax <= sv.bvh_origin_limit * kBvhRange64) {
@@ -261,6 +269,24 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
         {
             float4 nd[MeshNode<PLAIN>::n];    // the node each TRAV lane opens next (the prefetched copy does not outlive this loop)
             if constexpr (kMeshPipe) { if (state == S_TRAV) mesh_load_node<PLAIN>(nodes, resume != 0u ? resume_node : node, nd); }
+            if constexpr (kSplit) {
+                for (;;) {
+                    const bool trav = state == S_TRAV;
+                    const bool has_leaf = trav && pend.n != 0u, can_open = trav && pend.n == 0u && node != kNone;
+                    const uint32_t n_leaf = (uint32_t)__popcll(__ballot(has_leaf)), n_open = (uint32_t)__popcll(__ballot(can_open));
+                    if (n_leaf != 0u && n_leaf >= n_open) {         // the lanes with noted leaves read one each (2:1 / 1:2 / 4:1 measured: no better)
+                        if (has_leaf && !qleaf_read(ma, tpar, pend, qcnt, overflow, best_up, lq, tid, nleaf)) state = S_FLUSH;
+                    } else if (n_open != 0u) {                      // the others open their next node
+                        if (can_open) qnode_open<SPILL, kMeshStack>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
+                                                                    spill_stride, glane, nbox);
+                    }
+                    if (state == S_TRAV && pend.n == 0u && node == kNone) state = S_FIN;
+                    const unsigned long long m_trav = __ballot(state == S_TRAV);
+                    const uint32_t waiting = (uint32_t)__popcll(__ballot(state == S_FIN || state == S_FLUSH)) +
+                                             (queue_empty ? 0u : (uint32_t)__popcll(__ballot(state == S_IDLE)));
+                    if (waiting >= thresh || m_trav == 0ull) break;
+                }
+            } else
             for (;;) {
                 if (state == S_TRAV) {
                     if (!mesh_step<SPILL, PLAIN, kMeshStack>(nodes, ma, q, sr, tpar, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq, tid,

@@ -303,4 +303,113 @@ __device__ __forceinline__ bool mesh_step(const float4 *__restrict__ nodes, cons
     return !flush;
 }
 
+// ---- the step in two halves (64-byte nodes) ---------------------------------------------------------------------------------
+// mesh_step opens a node and reads the records of every leaf child the ray enters before it returns: in a wave the leaf
+// loop runs as often as the lane with the most leaf children needs, with most lanes idle.  Here a lane that opens a node
+// only NOTES its leaf children (their link words, at most 4) and the wave decides per iteration whether the lanes with
+// noted leaves read one each or the others open their next node -- whichever group is larger -- so either half runs with
+// at least half of the walking lanes.  A lane opens its next node only when it has no leaf left, so 4 slots suffice; a
+// noted leaf is read even if the bound has moved past its rectangle since (its records are then rejected by t_lo).
+struct MeshPending { uint32_t p0, p1, p2, p3, n; };
+
+template <bool SPILL, int STACK, class RAY>
+__device__ __forceinline__ void qnode_open(const float4 *__restrict__ nodes, const RAY &q, uint32_t &node, uint32_t &sp, bool &overflow,
+                                           float best_up, MeshPending &pend, uint32_t *lds_stack, uint32_t tid,
+                                           uint32_t *__restrict__ spill, uint32_t spill_entries, size_t spill_stride, size_t glane,
+                                           uint32_t &nbox)
+{
+    const float4 *np = nodes + 4 * (size_t)node;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const uint32_t w[4] = { __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w) };
+    const uint32_t qx[4] = { __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w) };
+    const uint32_t qy[4] = { __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w) };
+    const auto Ax = n0.z * q.ix, Ay = n0.w * q.iy;
+    const auto Bx = qnode_offset(n0.x, q.ix, q.nx), By = qnode_offset(n0.y, q.iy, q.ny);
+    float key[4];
+    uint32_t kl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float tc = qrect_entry(qx[c], qy[c], Ax, Bx, Ay, By, best_up, ray_slack(q));
+        const uint32_t type = w[c] >> kQNodeShift;
+        const bool in = tc < __builtin_inff();
+        if (in && type != 0u && type != kQNodeEmpty) {          // a leaf the ray enters: noted, read later
+            pend.p3 = pend.p2; pend.p2 = pend.p1; pend.p1 = pend.p0; pend.p0 = w[c];
+            pend.n += 1;
+        }
+        key[c] = type == 0u ? tc : __builtin_inff();
+        kl[c] = w[c] & kQNodeIndexMask;
+    }
+    nbox += 4;
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = kl[i]; kl[i] = kl[j]; kl[j] = tl; } }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                           (key[3] < __builtin_inff() ? 1u : 0u);
+    if (sp + 3u <= (uint32_t)STACK) {
+#pragma unroll
+        for (uint32_t i = 1; i <= 3; ++i) {
+            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;      // (row STACK = the sink)
+            lds_stack[(size_t)row * kBvhThreads + tid] = kl[i];
+        }
+        sp += npush;
+    } else {
+#define RTX_PUSH(v)                                                                                           \
+        {                                                                                                     \
+            if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; }           \
+            else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                         \
+                spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;                  \
+            } else overflow = true;                                                                           \
+        }
+        if (key[3] < __builtin_inff()) RTX_PUSH(kl[3])
+        if (key[2] < __builtin_inff()) RTX_PUSH(kl[2])
+        if (key[1] < __builtin_inff()) RTX_PUSH(kl[1])
+#undef RTX_PUSH
+    }
+    node = key[0] < __builtin_inff() ? kl[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;
+        node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+    }
+}
+
+// Reads the noted leaf on top: its records are filtered and bounded as in mesh_step.  Returns false (the leaf stays noted)
+// when the queue cannot take its records: the caller has the queue's candidates tested exactly first.
+__device__ __forceinline__ bool qleaf_read(const MeshArrays &ma, const TriFilterParams &tpar, MeshPending &pend, uint32_t &qcnt,
+                                           bool &overflow, float &best_up, uint32_t *lds_q, uint32_t tid, uint32_t &nleaf)
+{
+    const uint32_t link = pend.p0;
+    const uint32_t n = link >> kQNodeShift, first = link & kQNodeIndexMask;
+    if (!mesh_queue_room(lds_q, tid, qcnt, best_up, n)) {
+        if (qcnt != 0u) return false;
+        overflow = true;                       // (a leaf of more records than the queue has entries: the upload never builds one)
+    }
+    pend.p0 = pend.p1; pend.p1 = pend.p2; pend.p2 = pend.p3;
+    pend.n -= 1;
+    for (uint32_t k = 0; k < n; k += 2u) {
+        const float4 *rp = ma.tri_f32 + 2 * (size_t)(first + k);
+        const float4 A0 = rp[0], B0 = rp[1], A1 = rp[2], B1 = rp[3];      // (padded: the second pair may belong to the next leaf)
+        uint32_t m = (int)tri_filter_sign(A0, B0, tpar) >= 0 ? 1u : 0u;
+        if (k + 1u < n && (int)tri_filter_sign(A1, B1, tpar) >= 0) m |= 2u;
+        while (m != 0u) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const float4 *gp = ma.tri_geo + 2 * (size_t)(first + k + j);
+            const float4 g0 = gp[0], g1 = gp[1];
+            float thi;
+            const float tlo = tri_bounds(j == 0u ? A0 : A1, g0, g1, tpar, thi);
+            if (tlo <= best_up && tlo < __builtin_inff()) {
+                best_up = fminf(best_up, thi);
+                if (qcnt < (uint32_t)kMeshQueue) {
+                    lds_q[(size_t)qcnt * kBvhThreads + tid] = (first + k + j) | kQueueTri;
+                    lds_q[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                    qcnt += 1;
+                }
+            }
+        }
+    }
+    nleaf += n;
+    return true;
+}
+
 }  // namespace rtx

@@ -275,7 +275,7 @@ def test_bvh_invariants_on_the_benchmark_scenes(rtx):
     st = _host_scene(rtx, scenes.random_triangles(100000, 2))                    # C3
     assert st["flags"] == 2 + 4 + 8 and st["quantised_nodes"] == st["wide_nodes"] and st["tri_in_tree"] == st["tri_leaf_entries"] == st["tri_filter_records"]
     assert 45000 < st["tri_in_tree"] < 56000                                     # about half are culled for every direction
-    assert st["flat_nodes"] == st["wide_nodes"] and st["largest_leaf"] == 4                     # (the 64-byte nodes hold leaves of up to 6 records)
+    assert st["flat_nodes"] == st["wide_nodes"] and st["largest_leaf"] == 5                     # (the 64-byte nodes hold leaves of up to 6 records)
     st = _host_scene(rtx, scenes.mixed_scene(60, 50, 2, seed=21))                # joint root: spheres + triangles
     assert st["flags"] == 3 and st["sphere_leaf_entries"] == 60 and 0 < st["flat_nodes"] < st["wide_nodes"]
     st = _host_scene(rtx, scenes.three_spheres())                                # C1: too small for a tree
