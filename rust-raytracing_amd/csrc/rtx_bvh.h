@@ -293,7 +293,7 @@ inline BvhBuild build_bvh(const std::vector<BvhBox> &sphere_boxes, const std::ve
     out.origin_limit = 4.0 * scale + 1.0;
     out.abs_pad = out.origin_limit * (1.0 / 4194304.0);            // 2^-22 * limit: 4x the origin-rounding shift
     if (!(out.origin_limit < 1.0e28)) return BvhBuild();
-    if (sphere_boxes.size() + n_tri >= 0x20000000ull) return BvhBuild();          // node indices must stay below kBvhFlatNode
+    if (sphere_boxes.size() + n_tri >= 0x10000000ull) return BvhBuild();          // node / record indices must stay below 2^28 (kBvhFlatNode, the walk's leaf notes)
     if (tri_leaf_size < 1) tri_leaf_size = 1;
     if (tri_leaf_size > (uint32_t)kBvhTriLeafMax) tri_leaf_size = (uint32_t)kBvhTriLeafMax;
     out.nodes.reserve(2 * (sphere_boxes.size() + n_tri) + 8);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
     TriFilterParams tpar;
     float best_up = 0.f;
     uint32_t node = kNone, sp = 0, qcnt = 0, nbox = 0, nleaf = 0, resume = 0, resume_node = 0;
-    constexpr bool kSplit = RTX_MESH_SPLIT != 0 && PLAIN == 2;      // the step in two halves (rtx_mesh_step.h)
+    constexpr bool kSplit = RTX_MESH_SPLIT != 0 && PLAIN != 1;      // the step in two halves (rtx_mesh_step.h; not built for 96-byte-node trees)
     MeshPending pend;
     pend.p0 = pend.p1 = pend.p2 = pend.p3 = 0u; pend.n = 0u;
     bool overflow = false, tree_used = false;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
                 tri_filter_from_ray(sv, r.pos, r.dir, tpar);
                 make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
                 node = sv.bvh_root;              // wide node 0 (flagged when it is a footprint node)
-                if constexpr (kSplit) { node &= ~kBvhFlatNode; pend.n = 0u; }
+                if constexpr (kSplit) { if (PLAIN == 2) node &= ~kBvhFlatNode; pend.n = 0u; }
                 state = S_TRAV;
             } else {
                 if (omax <= sv.bvh_origin_limit * kBvhRange64) {
@@ -275,10 +275,19 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
                     const bool has_leaf = trav && pend.n != 0u, can_open = trav && pend.n == 0u && node != kNone;
                     const uint32_t n_leaf = (uint32_t)__popcll(__ballot(has_leaf)), n_open = (uint32_t)__popcll(__ballot(can_open));
                     if (n_leaf != 0u && n_leaf >= n_open) {         // the lanes with noted leaves read one each (2:1 / 1:2 / 4:1 measured: no better)
-                        if (has_leaf && !qleaf_read(ma, tpar, pend, qcnt, overflow, best_up, lq, tid, nleaf)) state = S_FLUSH;
+                        if (has_leaf) {
+                            bool ok;
+                            if constexpr (PLAIN == 2) ok = qleaf_read(ma, tpar, pend, qcnt, overflow, best_up, lq, tid, nleaf);
+                            else ok = jleaf_read(ma, sr, tpar, pend, qcnt, overflow, best_up, lq, tid, nleaf);
+                            if (!ok) state = S_FLUSH;
+                        }
                     } else if (n_open != 0u) {                      // the others open their next node
-                        if (can_open) qnode_open<SPILL, kMeshStack>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
-                                                                    spill_stride, glane, nbox);
+                        if (can_open) {
+                            if constexpr (PLAIN == 2) qnode_open<SPILL, kMeshStack>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
+                                                                                    spill_stride, glane, nbox);
+                            else jnode_open<SPILL, kMeshStack>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
+                                                               spill_stride, glane, nbox);
+                        }
                     }
                     if (state == S_TRAV && pend.n == 0u && node == kNone) state = S_FIN;
                     const unsigned long long m_trav = __ballot(state == S_TRAV);

@@ -412,4 +412,143 @@ __device__ __forceinline__ bool qleaf_read(const MeshArrays &ma, const TriFilter
     return true;
 }
 
+// ---- the same two halves for a joint tree (128-byte nodes: 3-D nodes and footprint nodes, sphere and triangle leaves) ---------
+// A noted leaf is one word: bit 31 = triangle leaf, bits 28-30 = its records (1..6; a sphere leaf has 1), bits 0-27 = the first
+// record / leaf entry (the upload keeps a tree below 2^28 shapes).
+constexpr uint32_t kJNoteTri = 0x80000000u, kJNoteShift = 28, kJNoteIndexMask = (1u << 28) - 1u;
+
+template <bool SPILL, int STACK, class RAY>
+__device__ __forceinline__ void jnode_open(const float4 *__restrict__ nodes, const RAY &q, uint32_t &node, uint32_t &sp, bool &overflow,
+                                           float best_up, MeshPending &pend, uint32_t *lds_stack, uint32_t tid,
+                                           uint32_t *__restrict__ spill, uint32_t spill_entries, size_t spill_stride, size_t glane,
+                                           uint32_t &nbox)
+{
+    const float4 *np = nodes + 8 * (size_t)(node & ~kBvhFlatNode);
+    float4 nd[8];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) nd[c] = np[c];
+    uint32_t lnk[4], cnt[4];
+    float tc[4];
+    if (node & kBvhFlatNode) {
+        lnk[0] = __float_as_uint(nd[4].x); lnk[1] = __float_as_uint(nd[4].y); lnk[2] = __float_as_uint(nd[4].z); lnk[3] = __float_as_uint(nd[4].w);
+        cnt[0] = __float_as_uint(nd[5].x); cnt[1] = __float_as_uint(nd[5].y); cnt[2] = __float_as_uint(nd[5].z); cnt[3] = __float_as_uint(nd[5].w);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tc[c] = rect_entry32(nd[c], q, best_up);
+    } else {
+        nd[6] = np[6]; nd[7] = np[7];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lnk[c] = __float_as_uint(nd[c].w); cnt[c] = __float_as_uint(nd[4 + c].w);
+            tc[c] = box_entry32(nd[c], nd[4 + c], q, best_up);
+        }
+    }
+    nbox += 4;
+    float key[4];
+    uint32_t kl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (tc[c] < __builtin_inff() && cnt[c] - 1u < 0x1FFFFu) {                 // a leaf the ray enters: noted, read later
+            const uint32_t note = ((cnt[c] & kBvhTriLeaf) ? kJNoteTri : 0u) | ((cnt[c] & 0xFFFFu) << kJNoteShift) | lnk[c];
+            pend.p3 = pend.p2; pend.p2 = pend.p1; pend.p1 = pend.p0; pend.p0 = note;
+            pend.n += 1;
+        }
+        key[c] = cnt[c] == 0u ? tc[c] : __builtin_inff();
+        kl[c] = lnk[c];
+    }
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = kl[i]; kl[i] = kl[j]; kl[j] = tl; } }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                           (key[3] < __builtin_inff() ? 1u : 0u);
+    if (sp + 3u <= (uint32_t)STACK) {
+#pragma unroll
+        for (uint32_t i = 1; i <= 3; ++i) {
+            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;      // (row STACK = the sink)
+            lds_stack[(size_t)row * kBvhThreads + tid] = kl[i];
+        }
+        sp += npush;
+    } else {
+#define RTX_PUSH(v)                                                                                           \
+        {                                                                                                     \
+            if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; }           \
+            else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                         \
+                spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;                  \
+            } else overflow = true;                                                                           \
+        }
+        if (key[3] < __builtin_inff()) RTX_PUSH(kl[3])
+        if (key[2] < __builtin_inff()) RTX_PUSH(kl[2])
+        if (key[1] < __builtin_inff()) RTX_PUSH(kl[1])
+#undef RTX_PUSH
+    }
+    node = key[0] < __builtin_inff() ? kl[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;
+        node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+    }
+}
+
+__device__ __forceinline__ bool jleaf_read(const MeshArrays &ma, const SphereRay &sr, const TriFilterParams &tpar, MeshPending &pend,
+                                           uint32_t &qcnt, bool &overflow, float &best_up, uint32_t *lds_q, uint32_t tid, uint32_t &nleaf)
+{
+    const uint32_t note = pend.p0;
+    const uint32_t n = (note >> kJNoteShift) & 7u, first = note & kJNoteIndexMask;
+    if (!mesh_queue_room(lds_q, tid, qcnt, best_up, n)) {
+        if (qcnt != 0u) return false;
+        overflow = true;
+    }
+    pend.p0 = pend.p1; pend.p1 = pend.p2; pend.p2 = pend.p3;
+    pend.n -= 1;
+    if (note & kJNoteTri) {
+        for (uint32_t k = 0; k < n; k += 2u) {
+            const float4 *rp = ma.tri_f32 + 2 * (size_t)(first + k);
+            const float4 A0 = rp[0], B0 = rp[1], A1 = rp[2], B1 = rp[3];      // (padded: the second pair may belong to the next leaf)
+            uint32_t m = (int)tri_filter_sign(A0, B0, tpar) >= 0 ? 1u : 0u;
+            if (k + 1u < n && (int)tri_filter_sign(A1, B1, tpar) >= 0) m |= 2u;
+            while (m != 0u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(m);
+                m &= m - 1u;
+                const float4 *gp = ma.tri_geo + 2 * (size_t)(first + k + j);
+                const float4 g0 = gp[0], g1 = gp[1];
+                float thi;
+                const float tlo = tri_bounds(j == 0u ? A0 : A1, g0, g1, tpar, thi);
+                if (tlo <= best_up && tlo < __builtin_inff()) {
+                    best_up = fminf(best_up, thi);
+                    if (qcnt < (uint32_t)kMeshQueue) {
+                        lds_q[(size_t)qcnt * kBvhThreads + tid] = (first + k + j) | kQueueTri;
+                        lds_q[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                        qcnt += 1;
+                    }
+                }
+            }
+        }
+    } else {
+        for (uint32_t k = 0; k < n; ++k) {
+            const float4 rec = ma.sphere_cr[first + k];                              // {c - centre, r}: bvh_traverse_spheres' bounds
+            const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+            const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+            const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
+            const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+            const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+            const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+            const float Dp = Dl + G;
+            if (Dp >= 0.0f) {
+                const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+                const float Dm = Dl - G;
+                const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+                if (tlo <= best_up && !(thi < 0.0f)) {
+                    if (tlo > sr.K) best_up = fminf(best_up, thi);
+                    if (qcnt < (uint32_t)kMeshQueue) {
+                        lds_q[(size_t)qcnt * kBvhThreads + tid] = ma.sphere_prims[first + k];
+                        lds_q[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                        qcnt += 1;
+                    }
+                }
+            }
+        }
+    }
+    nleaf += n;
+    return true;
+}
+
 }  // namespace rtx
