@@ -38,11 +38,21 @@ constexpr uint32_t kMeshWaves = RTX_MESH_WAVES;   // waves per SIMD (= workgroup
 #endif
 
 constexpr int kMeshStack = (RTX_MESH_WAVES <= 4 ? 39 : 160 / RTX_MESH_WAVES) - 1 - 2 * kMeshQueue;   // LDS stack entries per lane: (entries + 1 sink row + 2 * kMeshQueue) KB per workgroup
+// The queue-fed instance (rays in flight from the wavefront form's level 0) is built for RTX_MESH_WAVES_Q workgroups per CU:
+// with 3 it has 168 instead of 128 VGPRs (fewer spills around the f64 phase) and 37 LDS stack entries (C5's tree, 3 * 11 + 2
+// = 35, needs no HBM column).  Measured, whole wavefront launch: C3 37.9 -> 36.1 ms at 3 (5: 43.8), C5 band level; a joint tree's
+// instance stays at 4 (240k axis-aligned faces: 166 ms at 4, 169 at 3); generating its own rays the kernel wants 4 (C5 band
+// alone: 72.3 ms at 4, 80.4 at 3, 89.6 at 5).
+#ifndef RTX_MESH_WAVES_Q
+#define RTX_MESH_WAVES_Q 3
+#endif
+constexpr uint32_t kMeshWavesQ = RTX_MESH_WAVES_Q;
+constexpr int kMeshStackQ = 152 / RTX_MESH_WAVES_Q - 1 - 2 * kMeshQueue;      // (37 at 3: 150 KB per CU; at 159 KB only 2 workgroups fit)
 // QUEUE: the rays are not generated here but taken from `src`, a queue of rays in flight at path level 1 (the hybrid of
 // rtx_wavefront.hip: the primary rays of a mesh whose tree exceeds the L2s walk as packets there, and everything after the
 // first hit runs here, where the f64 phases of other waves fill the waits of the per-lane walks).
 template <bool SPILL, int PLAIN, bool QUEUE>
-__global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel(const SceneView *__restrict__ svp,
+__global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWaves) void trace_bvh_mesh_kernel(const SceneView *__restrict__ svp,
                                                                                  const RowsView *__restrict__ rvp,
                                                                                  double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                                  unsigned long long *__restrict__ work_counter,
@@ -54,7 +64,8 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
     const unsigned long long n_rays = QUEUE ? *src.count : rv.n_rays;
-    __shared__ uint32_t lds_stack[kMeshStack + 1][kBvhThreads];        // + the sink row of the branch-free pushes
+    constexpr int STACKN = QUEUE && PLAIN ? kMeshStackQ : kMeshStack;
+    __shared__ uint32_t lds_stack[STACKN + 1][kBvhThreads];            // + the sink row of the branch-free pushes
     __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];            // candidate entries, then their t_lo
     uint32_t *const ls = &lds_stack[0][0];
     uint32_t *const lq = &lds_q[0][0];
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
                     float4 nd[MeshNode<PLAIN>::n];
                     if constexpr (kMeshPipe) mesh_load_node<PLAIN>(nodes, node, nd);
                     while (node != kNone || resume != 0u) {
-                        if (mesh_step<SPILL, PLAIN, kMeshStack>(nodes, ma, q64, sr, tpar, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq,
+                        if (mesh_step<SPILL, PLAIN, STACKN>(nodes, ma, q64, sr, tpar, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq,
                                              tid, spill, spill_entries, spill_stride, glane, nbox, nleaf))
                             continue;
 #pragma unroll 1
@@ -283,9 +294,9 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
                         }
                     } else if (n_open != 0u) {                      // the others open their next node
                         if (can_open) {
-                            if constexpr (PLAIN == 2) qnode_open<SPILL, kMeshStack>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
+                            if constexpr (PLAIN == 2) qnode_open<SPILL, STACKN>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
                                                                                     spill_stride, glane, nbox);
-                            else jnode_open<SPILL, kMeshStack>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
+                            else jnode_open<SPILL, STACKN>(nodes, q, node, sp, overflow, best_up, pend, ls, tid, spill, spill_entries,
                                                                spill_stride, glane, nbox);
                         }
                     }
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(kBvhThreads, kMeshWaves) void trace_bvh_mesh_kernel
             } else
             for (;;) {
                 if (state == S_TRAV) {
-                    if (!mesh_step<SPILL, PLAIN, kMeshStack>(nodes, ma, q, sr, tpar, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq, tid,
+                    if (!mesh_step<SPILL, PLAIN, STACKN>(nodes, ma, q, sr, tpar, nd, node, sp, qcnt, overflow, best_up, resume, resume_node, ls, lq, tid,
                                           spill, spill_entries, spill_stride, glane, nbox, nleaf))
                         state = S_FLUSH;
                     else if (node == kNone) state = S_FIN;
@@ -347,7 +358,8 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
                               const MeshRaySource *src)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
-    const uint64_t cap = (uint64_t)n_cus * kMeshWaves;
+    const bool wide = src && (sv.bvh_flags & 4u) != 0u;          // the queue-fed instance of a pure footprint tree: fewer, fatter workgroups
+    const uint64_t cap = (uint64_t)n_cus * (wide ? kMeshWavesQ : kMeshWaves);
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
     // lanes that wait for the f64 phase before it runs (tuning knob).  Fed from a queue of bounced rays the kernel holds no
@@ -365,7 +377,8 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     la.tri_f32 = sv.tri_f32; la.tri_fidx = sv.tri_fidx; la.tris = sv.tris;
     MeshArrays ma;
     ma.sphere_cr = sv.bvh_leaf_cr; ma.sphere_prims = sv.bvh_prims; ma.tri_f32 = sv.tri_f32; ma.tri_geo = sv.tri_geo;
-    const uint32_t spill_entries = spill ? bvh_mesh_spill_entries(sv) : 0u;
+    const uint32_t need_stack = 3u * sv.bvh_depth + 2u, lds_stack = (uint32_t)(wide ? kMeshStackQ : kMeshStack);
+    const uint32_t spill_entries = spill && need_stack > lds_stack ? need_stack - lds_stack : 0u;
     // 0: a joint tree; 1: nothing but (x, y)-footprint triangles; 2: ... with the 64-byte nodes (RTX_HIP_NO_QNODES=1: A/B runs)
     const bool no_q = std::getenv("RTX_HIP_NO_QNODES") != nullptr;
     const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : ((sv.bvh_flags & 8u) != 0u && !no_q ? 2 : 1);
