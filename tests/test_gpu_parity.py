@@ -1030,8 +1030,8 @@ def test_empty_scene_with_more_rays_than_resident_slots(gpu):
 def test_render_devices_partition_is_invisible(gpu, oracle):
     """rtx_render_devices (multi-GPU behind the C ABI): the device list [0, 0] and [0, 0, 0] put two / three bands --
     separate handles, host threads and streams -- on this box's one GPU; the gathered, de-interleaved frame equals
-    rtx_render's bit for bit, for f64 and for the u8 epilogue, heights that do not divide evenly and a height smaller
-    than the device count."""
+    rtx_render's bit for bit, for f64 and for the u8 epilogue, heights that do not divide evenly, a height smaller
+    than the device count, and bands large enough for the kernels AUTO takes on large renders."""
     from rust_raytracing_amd import scenes
     objs = scenes.mixed_scene(60, 50, 2, seed=21)
     sc = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=3, seed=42), gpu.Camera(*scenes.CAMERA), objs)
@@ -1043,6 +1043,12 @@ def test_render_devices_partition_is_invisible(gpu, oracle):
         assert np.array_equal(sc.render_to_image(w, h, devices=[0, 0]), sc.render_to_image(w, h))
     big = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*scenes.CAMERA), scenes.random_spheres(10000, 1))
     assert np.array_equal(big.render(480, 270, devices=[0, 0]), big.render(480, 270))
+    # bands big enough for what AUTO takes on large renders: the two-stage sphere kernel (>= 2^20 rays per band) ...
+    assert np.array_equal(big.render(1203, 997, devices=[0, 0]), big.render(1203, 997))
+    # ... and the wavefront form of a mesh (packets over a band of interleaved rows, the regrouping kernel from their queue)
+    mesh = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*scenes.CAMERA),
+                                 scenes.light_every(scenes.compact(scenes.random_triangles(30000, 8), k=0.06, x0=5.0)))
+    assert np.array_equal(mesh.render(1203, 997, devices=[0, 0]), mesh.render(1203, 997))
     with pytest.raises(gpu.RtxError):
         sc.render(8, 8, devices=[])
     with pytest.raises(gpu.RtxError):
