@@ -23,8 +23,11 @@
  * RtxSceneHandle owns scratch memory and is for one thread at a time; upload one handle per rendering thread or rank.
  * Streams: a handle's device buffers are shared by all of its renders, so its work is ordered on one stream at a time --
  * a call that brings a different stream than the previous call first waits for the previous stream to drain.
- * With stats == NULL rtx_render_rows is asynchronous; an internal error of such a render (the sweep kernel's round-bound
- * watchdog) is reported by the next call on the handle that finds it, at the latest by rtx_scene_free.
+ * (on the device: an event the handle owns, recorded at the end of every render -- the caller's previous stream may be
+ * gone by then and is never touched again).
+ * With stats == NULL rtx_render_rows / rtx_render_blocks are asynchronous; an internal error of such a render (the launch's
+ * watchdog word: the sweep kernel's round bound, a full survivors' queue) is reported by the next call on the handle that
+ * finds it, at the latest by rtx_scene_free.
  */
 #ifndef RTX_HIP_H
 #define RTX_HIP_H
@@ -100,8 +103,25 @@ typedef struct RtxConfig {
     double   non_focal_offset;
     uint64_t seed;               /* counter-RNG key; the reference's fastrand stream is unseedable */
     uint32_t kernel;             /* RTX_KERNEL_* */
-    uint32_t reserved;           /* must be 0 */
+    uint32_t tuning;             /* RTX_TUNE_* bits: A/B switches for tests and lab runs; 0 = what ships */
 } RtxConfig;
+
+/* RtxConfig.tuning.  Every combination renders the same bits (tests/test_gpu_parity.py::test_ab_knobs_keep_the_bits);
+ * the library reads no environment variable for any of this.  The two tree-build fields (TRI_LEAF, BVH_MEDIAN) are read
+ * when the tree is built (rtx_scene_upload / rtx_scene_append_objects / rtx_render), the others per render. */
+enum {
+    RTX_TUNE_NO_TILES    = 1u << 0,  /* BVH kernels: ray queue in image rows instead of 8x8 pixel tiles (no packets then) */
+    RTX_TUNE_BVH_CLASSIC = 1u << 1,  /* round 1's trace_bvh_kernel / trace_bvh_regroup_kernel instead of the f32-only steps */
+    RTX_TUNE_NO_QNODES   = 1u << 2,  /* 96-byte footprint nodes instead of the 64-byte quantised ones */
+    RTX_TUNE_NO_PACKETS  = 1u << 3,  /* primary rays walk per lane instead of one wave-uniform walk per tile */
+    RTX_TUNE_WF_PURE     = 1u << 4,  /* RTX_KERNEL_WAVEFRONT on a pure (x, y)-footprint tree: every level in that form */
+    RTX_TUNE_ONE_STAGE   = 1u << 5,  /* sphere trees: primary and bounced rays in one launch whatever the ray count */
+    RTX_TUNE_TWO_STAGE   = 1u << 6,  /* sphere trees: two stages even below 2^20 rays per launch */
+    RTX_TUNE_BVH_MEDIAN  = 1u << 7,  /* tree build: median splits instead of the binned SAH */
+    RTX_TUNE_TRI_LEAF_SHIFT = 8,     /* bits 8..11: triangles per leaf, 1..6 (0 = default: 5 pure footprint tree, 2 joint) */
+    RTX_TUNE_THRESH_SHIFT   = 12     /* bits 12..18: lanes that wait before the regrouping kernels' f64 phase runs, 1..64
+                                        (0 = default) */
+};
 
 /* Camera (camera.rs:7-15).  to_world_space / to_cam_space are the three ROWS of each matrix
  * (mat.rs:11-18), row-major.  Only fov, position and to_world_space are read by render
@@ -148,7 +168,7 @@ typedef struct RtxSceneHandle_ *RtxSceneHandle;
 RTX_STATIC_ASSERT(sizeof(RtxObject) == 136 && offsetof(RtxObject, geom) == 8 && offsetof(RtxObject, base_color) == 80 &&
                   offsetof(RtxObject, emission_color) == 104 && offsetof(RtxObject, roughness) == 128, "RtxObject layout");
 RTX_STATIC_ASSERT(sizeof(RtxConfig) == 56 && offsetof(RtxConfig, focal_length) == 16 && offsetof(RtxConfig, seed) == 40 &&
-                  offsetof(RtxConfig, kernel) == 48 && offsetof(RtxConfig, reserved) == 52, "RtxConfig layout");
+                  offsetof(RtxConfig, kernel) == 48 && offsetof(RtxConfig, tuning) == 52, "RtxConfig layout");
 RTX_STATIC_ASSERT(sizeof(RtxCamera) == 200 && offsetof(RtxCamera, position) == 8 && offsetof(RtxCamera, direction) == 32 &&
                   offsetof(RtxCamera, to_cam_space) == 56 && offsetof(RtxCamera, to_world_space) == 128, "RtxCamera layout");
 RTX_STATIC_ASSERT(sizeof(RtxScene) == 272 && offsetof(RtxScene, camera) == 56 && offsetof(RtxScene, n_objects) == 256 &&
@@ -176,10 +196,11 @@ int32_t rtx_render_to_image(const RtxScene *scene, uint32_t width, uint32_t heig
 
 /* Scene::render / render_to_image on several GPUs of one node (BASELINE north_star: "tile-partitioned across the 8 GPUs
  * ... single gather over xGMI at the end"): still ONE call that returns the whole frame (scene.rs:144-170).  The scene is
- * packed once and replicated; device devices[k] renders the interleaved row band y = k, k + n, ... (one host thread and
- * one stream per device, no exchange during the render: pixels are independent, scene.rs:149-160); the bands are gathered
- * on devices[0] with one peer copy each (hipMemcpyPeerAsync: every peer pushes over its own xGMI link; no communicator
- * to set up), de-interleaved there and copied to the host once.  Pixel values do not depend on n_devices or the order of
+ * packed once and replicated; device devices[k] renders the blocks of 8 rows k, k + n, ... (rtx_render_blocks; one host
+ * thread and one stream per device, no exchange during the render: pixels are independent, scene.rs:149-160); the bands --
+ * for render_to_image already quantised to 3 bytes per pixel -- are gathered on devices[0] with one peer copy each
+ * (hipMemcpyPeerAsync: every peer pushes over its own xGMI link; no communicator to set up), de-interleaved there and
+ * copied to the host once.  Pixel values do not depend on n_devices or the order of
  * the list.  An entry may repeat (two bands on one device) -- that is how the path is tested on a one-GPU box.
  * rtx_render(scene, w, h, out) == rtx_render_devices(scene, w, h, {0}, 1, out). */
 int32_t rtx_render_devices(const RtxScene *scene, uint32_t width, uint32_t height,
@@ -193,6 +214,11 @@ int32_t rtx_scene_free(RtxSceneHandle scene);      /* non-zero: an earlier async
 
 /* Replace the Config of an uploaded scene (rays_per_pixel, seed, kernel, ...). */
 int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config);
+
+/* Upper bound of the per-render scratch this handle allocates on its device (sample records, ray queues), in bytes;
+ * 0 = the default (24 GiB, never more than 3/4 of the memory free at render time).  A frame that needs more is traced in
+ * sample batches -- same bits (the fold continues across batches).  For several handles, ranks or frameworks sharing a GPU. */
+int32_t rtx_scene_set_scratch_limit(RtxSceneHandle scene, uint64_t bytes);
 
 /* Scene::add_object (scene.rs:126-128) on an uploaded scene: the objects are appended in order (they get the next scene
  * indices, so earlier objects still win ties, scene.rs:250), the shape arrays, filter records and the BVH are rebuilt on
@@ -217,6 +243,21 @@ int32_t rtx_scene_set_camera(RtxSceneHandle scene, const RtxCamera *camera);
 int32_t rtx_render_rows(RtxSceneHandle scene, uint32_t width, uint32_t height,
                         uint32_t row_begin, uint32_t row_stride, uint32_t n_rows,
                         double *d_out_rgb, void *stream, RtxStats *stats);
+
+/*
+ * The same for a band made of BLOCKS of rows -- what one rank / device of a multi-GPU job renders.  The frame is cut into
+ * blocks of block_rows rows (block b = image rows [b * block_rows, min((b + 1) * block_rows, height))), dealt out
+ * round-robin: part `part` of `n_parts` owns blocks part, part + n_parts, ...  d_out_rgb: DEVICE buffer of
+ * rtx_blocks_row_count(height, block_rows, part, n_parts) * width * 3 doubles, the part's rows in increasing image order.
+ * block_rows = 8 keeps the BVH kernels' 8x8 ray tiles whole (a tile of rtx_render_rows' single-row bands is 8 columns x
+ * 8 * n_parts image rows: the packet walks lose a quarter to a third of their rate on it); the interleaving still balances
+ * the uneven per-pixel cost (1080 rows on 8 parts: 17 or 16 blocks each).  Pixels do not depend on the partition.
+ * rtx_render_blocks(h, w, hgt, 1, r, n, ...) == rtx_render_rows(h, w, hgt, r, n, rows, ...).
+ */
+uint32_t rtx_blocks_row_count(uint32_t height, uint32_t block_rows, uint32_t part, uint32_t n_parts);
+int32_t rtx_render_blocks(RtxSceneHandle scene, uint32_t width, uint32_t height,
+                          uint32_t block_rows, uint32_t part, uint32_t n_parts,
+                          double *d_out_rgb, void *stream, RtxStats *stats);
 
 /* Device epilogue of render_to_image on a full device image (scene.rs:175-178):
  * d_rgb height*width*3 doubles -> d_rgb8 height*width*3 bytes, flipped vertically. */

@@ -19,6 +19,8 @@ import math
 import numpy as np
 
 from . import abi
+from .abi import (RTX_TUNE_NO_TILES, RTX_TUNE_BVH_CLASSIC, RTX_TUNE_NO_QNODES, RTX_TUNE_NO_PACKETS, RTX_TUNE_WF_PURE, RTX_TUNE_ONE_STAGE,
+                  RTX_TUNE_TWO_STAGE, RTX_TUNE_BVH_MEDIAN, RTX_TUNE_TRI_LEAF_SHIFT, RTX_TUNE_THRESH_SHIFT)
 from .abi import (OBJECT_DTYPE, RTX_KERNEL_WAVEFRONT, RTX_KERNEL_AUTO, RTX_KERNEL_BVH, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH_REGROUP,
                   RTX_PLANE, RTX_SPHERE, RTX_TRIANGLE, RtxError, load_library)
 
@@ -159,7 +161,7 @@ def pack_objects(objects):
 # ---------------------------------------------------------------------------------------------
 class Config:
     def __init__(self, rays_per_pixel=16, max_bounces=10, focal_length=10.0, focal_offset=1e-4,
-                 non_focal_offset=1e-1, seed=42, kernel=RTX_KERNEL_AUTO):          # Default, scene.rs:55-65
+                 non_focal_offset=1e-1, seed=42, kernel=RTX_KERNEL_AUTO, tuning=0):   # Default, scene.rs:55-65
         self.rays_per_pixel = int(rays_per_pixel)
         self.max_bounces = int(max_bounces)
         self.focal_length = float(focal_length)
@@ -167,6 +169,7 @@ class Config:
         self.non_focal_offset = float(non_focal_offset)
         self.seed = int(seed)
         self.kernel = int(kernel)
+        self.tuning = int(tuning)                                   # RTX_TUNE_* bits (A/B switches; 0 = what ships)
 
     @staticmethod
     def default():
@@ -174,7 +177,7 @@ class Config:
 
     def _with(self, **kw):                                          # reassign!, scene.rs:29-37
         c = Config(self.rays_per_pixel, self.max_bounces, self.focal_length, self.focal_offset,
-                   self.non_focal_offset, self.seed, self.kernel)
+                   self.non_focal_offset, self.seed, self.kernel, self.tuning)
         for k, v in kw.items():
             setattr(c, k, v)
         return c
@@ -200,9 +203,12 @@ class Config:
     def with_kernel(self, v):
         return self._with(kernel=int(v))
 
+    def with_tuning(self, v):
+        return self._with(tuning=int(v))
+
     def to_c(self):
         return abi.RtxConfig(self.rays_per_pixel, self.max_bounces, self.focal_length, self.focal_offset,
-                             self.non_focal_offset, self.seed & 0xFFFFFFFFFFFFFFFF, self.kernel, 0)
+                             self.non_focal_offset, self.seed & 0xFFFFFFFFFFFFFFFF, self.kernel, self.tuning)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -344,6 +350,10 @@ class SceneHandle:
         c = config.to_c()
         abi.check(self._lib.rtx_scene_set_config(self._h, C.byref(c)))
 
+    def set_scratch_limit(self, n_bytes):
+        """Upper bound of the handle's per-render scratch (0 = default); larger frames are traced in sample batches, same bits."""
+        abi.check(self._lib.rtx_scene_set_scratch_limit(self._h, int(n_bytes)))
+
     def set_camera(self, camera):
         c = camera.to_c()
         abi.check(self._lib.rtx_scene_set_camera(self._h, C.byref(c)))
@@ -361,6 +371,14 @@ class SceneHandle:
                                             int(n_rows), C.c_void_p(int(d_out_ptr)),
                                             C.c_void_p(int(stream)) if stream else None,
                                             C.byref(stats) if want_stats else None))
+        return stats if want_stats else None
+
+    def render_blocks(self, width, height, block_rows, part, n_parts, d_out_ptr, stream=None, want_stats=True):
+        """The band of part `part` of `n_parts` (blocks of `block_rows` rows dealt out round-robin) into device memory."""
+        stats = abi.RtxStats()
+        abi.check(self._lib.rtx_render_blocks(self._h, int(width), int(height), int(block_rows), int(part), int(n_parts),
+                                              C.c_void_p(int(d_out_ptr)), C.c_void_p(int(stream)) if stream else None,
+                                              C.byref(stats) if want_stats else None))
         return stats if want_stats else None
 
     def close(self):

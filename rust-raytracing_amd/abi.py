@@ -14,6 +14,10 @@ LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(HERE, "librtx_hip.so") 
 RTX_SPHERE, RTX_PLANE, RTX_TRIANGLE = 0, 1, 2
 RTX_KERNEL_AUTO, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH, RTX_KERNEL_BVH_REGROUP = 0, 1, 2, 3, 4, 5
 RTX_KERNEL_WAVEFRONT = 6
+# RtxConfig.tuning bits (include/rtx_hip.h): A/B switches, every combination renders the same bits
+RTX_TUNE_NO_TILES, RTX_TUNE_BVH_CLASSIC, RTX_TUNE_NO_QNODES, RTX_TUNE_NO_PACKETS = 1, 2, 4, 8
+RTX_TUNE_WF_PURE, RTX_TUNE_ONE_STAGE, RTX_TUNE_TWO_STAGE, RTX_TUNE_BVH_MEDIAN = 16, 32, 64, 128
+RTX_TUNE_TRI_LEAF_SHIFT, RTX_TUNE_THRESH_SHIFT = 8, 12
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)
@@ -27,7 +31,7 @@ assert OBJECT_DTYPE.itemsize == 136
 class RtxConfig(C.Structure):
     _fields_ = [("rays_per_pixel", C.c_uint64), ("max_bounces", C.c_uint64),
                 ("focal_length", C.c_double), ("focal_offset", C.c_double), ("non_focal_offset", C.c_double),
-                ("seed", C.c_uint64), ("kernel", C.c_uint32), ("reserved", C.c_uint32)]
+                ("seed", C.c_uint64), ("kernel", C.c_uint32), ("tuning", C.c_uint32)]
 
 
 class RtxCamera(C.Structure):
@@ -60,10 +64,14 @@ SYMBOLS = [
     ("rtx_scene_upload", C.c_int32, [C.POINTER(RtxScene), C.c_int32, C.POINTER(C.c_void_p)]),
     ("rtx_scene_free", C.c_int32, [C.c_void_p]),
     ("rtx_scene_set_config", C.c_int32, [C.c_void_p, C.POINTER(RtxConfig)]),
+    ("rtx_scene_set_scratch_limit", C.c_int32, [C.c_void_p, C.c_uint64]),
     ("rtx_scene_set_camera", C.c_int32, [C.c_void_p, C.POINTER(RtxCamera)]),
     ("rtx_scene_append_objects", C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("rtx_render_rows", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.POINTER(RtxStats)]),
+    ("rtx_blocks_row_count", C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("rtx_render_blocks", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.POINTER(RtxStats)]),
     ("rtx_quantize_image_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
     ("rtx_debug_math", C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("rtx_debug_host_scene", C.c_int32, [C.POINTER(RtxScene), C.POINTER(C.c_uint64)]),

@@ -49,29 +49,28 @@ int usable_device_count()
     return ok;
 }
 
-size_t scratch_cap_bytes()
-{
-    // per-render scratch of one handle: sized for a 288 GB part (24 GiB: a C2 frame of 64 spp -- 17.5 GB of sample records and
-    // queue -- and 59 M rays of the wavefront form run as one launch; fewer, larger launches measured 3-10 % faster)
-    const char *e = std::getenv("RTX_HIP_SCRATCH_MB");
-    size_t mb = 24576;
-    if (e && *e) { long v = std::strtol(e, nullptr, 10); if (v > 0) mb = (size_t)v; }
-    return mb << 20;
-}
+// per-render scratch of one handle: sized for a 288 GB part (24 GiB: a C2 frame of 64 spp -- 12.7 GB of sample records and
+// queue -- and 59 M rays of the wavefront form run as one launch; fewer, larger launches measured 3-10 % faster)
+constexpr size_t kDefaultScratchBytes = (size_t)24576 << 20;
 
-// Triangles per BVH leaf; RTX_HIP_TRI_LEAF is a tuning knob (1..6: a leaf must fit the walk's 6-entry candidate queue, or
-// every visit of it ends in the exhaustive sweep).  A tree of (x, y) footprints alone (`plain`: C3, C5) gets 5: a packet tests
-// a leaf's records for 64 rays at once and the regrouping kernel's leaf half reads one leaf per lane per iteration
-// (rtx_mesh_step.h), so fewer, fuller leaves pay.  Measured, C3 1080p x 8 / C5 band x 4 in ms, the wavefront form | the
-// regrouping kernel alone:  3: 41.7 / 59.5 | 79.8 / 75.2,  4: 39.5 / 56.4 | 76.5 / 72.3,  5: 38.0 / 55.2 | 77.4 / 72.1,
+// Triangles per BVH leaf (RTX_TUNE_TRI_LEAF_SHIFT bits of RtxConfig.tuning: 1..6 -- a leaf must fit the walk's 6-entry
+// candidate queue, or every visit of it ends in the exhaustive sweep).  A tree of (x, y) footprints alone (`plain`: C3, C5)
+// gets 5: a packet tests a leaf's records for 64 rays at once and the regrouping kernel's leaf half reads one leaf per lane
+// per iteration (rtx_mesh_step.h), so fewer, fuller leaves pay.  Measured, C3 1080p x 8 / C5 band x 4 in ms, the wavefront
+// form | the regrouping kernel alone:  3: 41.7 / 59.5 | 79.8 / 75.2,  4: 39.5 / 56.4 | 76.5 / 72.3,  5: 38.0 / 55.2 | 77.4 / 72.1,
 // 6: 38.6 / 56.6 | 78.9 / 74.0  (2, before the step was split: 53.2 / 72.6 | 99.2 / 94.7).  A joint tree keeps 2 (240k axis-aligned
 // faces: 222 ms at 2, 242 at 4).
-uint32_t tri_leaf_size(bool plain)
+uint32_t tri_leaf_size(bool plain, uint32_t tuning)
 {
-    const char *e = std::getenv("RTX_HIP_TRI_LEAF");
-    long v = plain ? 5 : 2;
-    if (e && *e) v = std::strtol(e, nullptr, 10);
-    return (uint32_t)(v < 1 ? 1 : (v > (long)kQNodeLeafMax ? (long)kQNodeLeafMax : v));
+    const uint32_t t = (tuning >> RTX_TUNE_TRI_LEAF_SHIFT) & 15u;
+    const uint32_t v = t ? t : (plain ? 5u : 2u);
+    return v > kQNodeLeafMax ? kQNodeLeafMax : v;
+}
+
+bool debug_prints()
+{
+    static const bool on = std::getenv("RTX_HIP_DEBUG") != nullptr;      // diagnostics on stderr only; changes no result
+    return on;
 }
 
 }  // namespace
@@ -98,8 +97,11 @@ struct RtxSceneHandle_ {
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
     // The handle's device buffers (descriptors, tables, counters, scratch) are shared by all of its renders, so they
     // are ordered on ONE stream at a time: when a call brings a different stream the previous one is drained first.
-    hipStream_t last_stream = nullptr;
+    size_t scratch_limit = 0;                             // rtx_scene_set_scratch_limit (0 = default)
+    hipStream_t last_stream = nullptr;                    // compared, never used: the caller may have destroyed it since
     bool have_last_stream = false;
+    hipEvent_t ev_done = nullptr;                         // recorded at the end of every render, on the stream it ran on
+    bool have_done = false;
     // Round-bound watchdog of the sweep kernel (ctr[1].pad_): copied to this pinned word after every launch and looked
     // at by the next entry point that finds the copy complete (and by rtx_scene_free), so that the asynchronous
     // stats == NULL path reports it too.
@@ -107,7 +109,7 @@ struct RtxSceneHandle_ {
     hipEvent_t ev_watchdog = nullptr;
     bool watchdog_pending = false;
     // what the trig tables currently hold
-    uint32_t t_w = 0, t_h = 0, t_rb = 0, t_rs = 0, t_nr = 0;
+    uint32_t t_w = 0, t_h = 0, t_rb = 0, t_rs = 0, t_blk = 0, t_nr = 0;
     double t_fov = 0.0;
     bool t_valid = false;
 };
@@ -136,6 +138,7 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
     h->sv.focal_offset = cfg.focal_offset;
     h->sv.non_focal_offset = cfg.non_focal_offset;
     h->sv.seed = cfg.seed;
+    h->sv.tuning = cfg.tuning;
     h->sv_dirty = true;
 }
 
@@ -175,6 +178,7 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->d_rv) (void)hipFree(h->d_rv);
     if (h->h_watchdog) (void)hipHostFree(h->h_watchdog);
     if (h->ev_watchdog) (void)hipEventDestroy(h->ev_watchdog);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -330,10 +334,10 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
     for (size_t k = 0; k < spheres.size() && spheres_finite; ++k)
         spheres_finite = sphere_box(scene->objects[sphere_id[k]].geom, sphere_boxes[k]);
     if (!spheres_finite || sphere_boxes.size() <= 4) sphere_boxes.clear();
-    const bool use_sah = [] { const char *e = std::getenv("RTX_HIP_BVH_MEDIAN"); return !(e && *e && *e != '0'); }();   // tuning knob
+    const bool use_sah = (scene->config.tuning & RTX_TUNE_BVH_MEDIAN) == 0u;
     BvhBuild &bvh = p.bvh;
     const bool plain_tree = sphere_boxes.empty() && tri_boxes[0].empty() && tri_boxes[1].empty();   // (x, y) footprints alone (free axis 2)
-    bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(plain_tree), use_sah);
+    bvh = build_bvh(sphere_boxes, tri_boxes, tri_leaf_size(plain_tree, scene->config.tuning), use_sah);
     Bvh4Build &bvh4 = p.bvh4;
     bvh4 = collapse_to_bvh4(bvh);
 
@@ -383,7 +387,7 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
                      (bvh.has_tris && !bvh.has_spheres && tree_recs[1].empty() && tree_recs[0].empty() ? 4u : 0u);
     if ((p.sv.bvh_flags & 4u) && build_qnodes(bvh4, p.qnodes)) p.sv.bvh_flags |= 8u;
     else p.qnodes.clear();
-    if (std::getenv("RTX_HIP_DEBUG"))
+    if (debug_prints())
         std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree: %zu xy / %zu xz / %zu yz footprints, %zu tested per segment), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
                      spheres.size(), tris.size(), n_in_tree, tree_recs[2].size(), tree_recs[1].size(), tree_recs[0].size(),
                      demoted.size() + always_recs.size(), bvh.nodes.size(), bvh4.nodes.size(), bvh4.depth);
@@ -416,7 +420,7 @@ int32_t upload_packed(RtxSceneHandle_ *h, const PackedScene &p)
         SceneView sv = p.sv;
         sv.rays_per_pixel = h->sv.rays_per_pixel; sv.max_bounces = h->sv.max_bounces;
         sv.focal_length = h->sv.focal_length; sv.focal_offset = h->sv.focal_offset; sv.non_focal_offset = h->sv.non_focal_offset;
-        sv.seed = h->sv.seed;
+        sv.seed = h->sv.seed; sv.tuning = h->sv.tuning;
         h->sv = sv;
     }
     h->sv.cam_pos = mk(h->cam.position[0], h->cam.position[1], h->cam.position[2]);
@@ -498,6 +502,7 @@ int32_t create_handle(const RtxScene *scene, const PackedScene &p, int32_t devic
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_rv, sizeof(RowsView));
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_watchdog, sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) { *h->h_watchdog = 0ull; e = hipEventCreateWithFlags(&h->ev_watchdog, hipEventDisableTiming); }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
     for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
     if (e != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, std::string("scene scratch: ") + hipGetErrorString(e)); }
     *out = h;
@@ -518,16 +523,18 @@ int32_t check_watchdog(RtxSceneHandle_ *h, bool wait)
     if (*h->h_watchdog != 0ull) {
         const unsigned long long n = *h->h_watchdog;
         *h->h_watchdog = 0ull;
-        return fail(RTX_ERR_HIP, "an earlier render on this scene hit the sweep kernel's round bound (internal error): " +
-                                     std::to_string(n) + " workgroup(s) left early; its image is incomplete");
+        return fail(RTX_ERR_HIP, "an earlier render on this scene raised its watchdog word (internal error: the sweep kernel's round "
+                                 "bound, or a full survivors' queue): " + std::to_string(n) + " event(s); its image is incomplete");
     }
     return RTX_OK;
 }
 
-// Orders a call on `stream` after everything the handle enqueued on the stream it used before.
+// Orders a call on `stream` after everything the handle enqueued on the stream it used before: the new stream waits, on
+// the device, for the event the previous render recorded at its end.  The previous stream handle itself is not touched (a
+// caller that rotates streams may have destroyed it) and the host does not block.
 int32_t adopt_stream(RtxSceneHandle_ *h, hipStream_t stream)
 {
-    if (h->have_last_stream && h->last_stream != stream) RTX_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    if (h->have_last_stream && h->last_stream != stream && h->have_done) RTX_HIP_CHECK(hipStreamWaitEvent(stream, h->ev_done, 0));
     h->last_stream = stream;
     h->have_last_stream = true;
     return RTX_OK;
@@ -602,6 +609,13 @@ int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config)
     return RTX_OK;
 }
 
+int32_t rtx_scene_set_scratch_limit(RtxSceneHandle scene, uint64_t bytes)
+{
+    if (!scene) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_set_scratch_limit: null scene");
+    scene->scratch_limit = (size_t)bytes;
+    return RTX_OK;
+}
+
 int32_t rtx_scene_set_camera(RtxSceneHandle scene, const RtxCamera *camera)
 {
     if (!scene || !camera) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_scene_set_camera: null argument");
@@ -635,17 +649,29 @@ int32_t rtx_scene_append_objects(RtxSceneHandle scene, const RtxObject *objects,
     return RTX_OK;
 }
 
-int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_stride,
-                        uint32_t n_rows, double *d_out_rgb, void *stream_, RtxStats *stats)
+}  // extern "C"
+
+// Rows of part `part` of `n_parts` when the frame is cut into blocks of `block` rows dealt out round-robin.
+static uint32_t blocks_row_count(uint32_t height, uint32_t block, uint32_t part, uint32_t n_parts)
 {
-    if (!h) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: null scene");
+    if (block == 0 || n_parts == 0 || part >= n_parts) return 0;
+    const uint64_t n_blocks = ((uint64_t)height + block - 1) / block;
+    if (part >= n_blocks) return 0;
+    const uint64_t mine = (n_blocks - part + n_parts - 1) / n_parts;            // blocks part, part + n_parts, ...
+    uint64_t rows = mine * block;
+    const uint64_t last = part + (mine - 1) * (uint64_t)n_parts;                // my last block; only the frame's last block can be partial
+    if (last == n_blocks - 1) rows -= n_blocks * block - height;
+    return (uint32_t)rows;
+}
+
+// The band local row k -> image row row_begin + (k / row_block) * row_stride + k % row_block, k < n_rows (rtx_device.h, image_row).
+static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_stride,
+                           uint32_t row_block, uint32_t n_rows, double *d_out_rgb, void *stream_, RtxStats *stats)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n_rows == 0 || width == 0) return RTX_OK;
     if (!d_out_rgb) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: null output");
-    if (row_stride == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: row_stride == 0");
-    if ((uint64_t)row_begin + (uint64_t)(n_rows - 1) * row_stride >= height)
-        return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: rows exceed the image height");
     if ((uint64_t)n_rows * width > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: more than 2^32 pixels per call");
     RTX_HIP_CHECK(hipSetDevice(h->device));
     if (int32_t rc = check_watchdog(h, false)) return rc;
@@ -672,6 +698,8 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     const uint64_t outside_tree = ((h->sv.bvh_flags & 1u) ? 0u : h->sv.n_spheres) +
                                   (uint64_t)(h->sv.n_tri_filter - h->sv.n_tri_tree);
     uint32_t kernel = h->cfg.kernel;
+    const uint32_t tuning = h->cfg.tuning;
+    const bool want_tiles = (tuning & RTX_TUNE_NO_TILES) == 0u, classic = (tuning & RTX_TUNE_BVH_CLASSIC) != 0u;
     if (kernel == RTX_KERNEL_AUTO) {
         if (h->sv.n_bvh_nodes != 0 && outside_tree <= 64) {
             const bool mesh = (h->sv.bvh_flags & 2u) != 0u && h->sv.n_tri_tree >= 1024u;
@@ -682,8 +710,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             // 315 vs 166 Mrays/s, 960x540x8 272 vs 163, 480x270x8 160 vs 130; C5 band (1M triangles) 57 vs 44
             // (a joint tree -- spheres, faces solved in other planes -- takes the same form when its level 0 can walk as
             // packets: 240k axis-aligned cube faces at 1080p x 8: 74.5 vs 46.7 Mrays/s, with 2k spheres 65.0 vs 43.2)
-            if (mesh && (uint64_t)npix * spp >= (1ull << 20) && wavefront_mesh_supported(h->sv, !std::getenv("RTX_HIP_NO_TILES")) &&
-                !std::getenv("RTX_HIP_NO_TILES"))
+            if (mesh && (uint64_t)npix * spp >= (1ull << 20) && want_tiles && wavefront_mesh_supported(h->sv, true))
                 kernel = RTX_KERNEL_WAVEFRONT;
         } else {
             kernel = RTX_KERNEL_MIXED;
@@ -692,12 +719,12 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     // the wavefront form exists for pure (x, y)-footprint triangle trees and for trees that hold spheres only; any other
     // scene takes the regrouping kernel
-    const bool wf_mesh = wavefront_mesh_supported(h->sv, !std::getenv("RTX_HIP_NO_TILES"));
+    const bool wf_mesh = wavefront_mesh_supported(h->sv, want_tiles);
     const bool wf_spheres = !wf_mesh && h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 3u) == 1u;
     if (kernel == RTX_KERNEL_WAVEFRONT && !wf_mesh && !wf_spheres) kernel = RTX_KERNEL_BVH_REGROUP;
     // the BVH kernels' ray queue runs over 8x8 pixel tiles (a wave's 64 rays = one tile); a sample then has
     // tiles_x * tiles_y * 64 queue slots (the padding of partial tiles included), else npix
-    const bool tiled = (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP || kernel == RTX_KERNEL_WAVEFRONT) && !std::getenv("RTX_HIP_NO_TILES");
+    const bool tiled = (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP || kernel == RTX_KERNEL_WAVEFRONT) && want_tiles;
     const uint32_t tiles_x = tiled ? (width + 7u) / 8u : 0u;
     const uint64_t per_sample64 = tiled ? (uint64_t)tiles_x * ((n_rows + 7u) / 8u) * 64u : (uint64_t)npix;
     if (per_sample64 > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: more than 2^32 ray slots per sample");
@@ -706,11 +733,20 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     uint64_t batch = spp;
     {
         // bytes per ray of a batch: the 32-byte sample record (+ the wavefront kernels' state, ~270 B)
-        // (+ the survivors' queue of the sphere kernel's two-stage form, 100 B)
+        // (+ the survivors' queue of the sphere kernel's two-stage form, 64 B)
         const bool sph2 = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0;
         const uint64_t per_ray = 4 * sizeof(double) + (kernel == RTX_KERNEL_WAVEFRONT ? wavefront_state_bytes(1u << 20, 1) >> 20 : 0) +
-                                 (sph2 ? 12 * sizeof(double) + sizeof(uint32_t) : 0);
-        const uint64_t fit = scratch_cap_bytes() / (per_sample64 * per_ray);
+                                 (sph2 ? 64 : 0);
+        // the cap: the handle's limit, never more than 3/4 of what is free on the device now (other handles, ranks or
+        // frameworks may share it; what this handle already holds counts as free for it)
+        size_t cap_bytes = h->scratch_limit ? h->scratch_limit : kDefaultScratchBytes;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t mine = h->samples_bytes + h->wf_bytes;
+            const size_t avail = (free_b + mine) / 4 * 3;
+            if (cap_bytes > avail) cap_bytes = avail;
+        } else (void)hipGetLastError();
+        const uint64_t fit = cap_bytes / (per_sample64 * per_ray);
         const uint64_t fit32 = 0xFFFFFFF0ull / per_sample64;
         if (batch > fit) batch = fit ? fit : 1;
         if (batch > fit32) batch = fit32;
@@ -719,9 +755,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row
     const size_t tdbl = 2 * (size_t)width + 2 * (size_t)n_rows;
     const bool t_same = h->t_valid && h->t_w == width && h->t_h == height && h->t_rb == row_begin &&
-                        h->t_rs == row_stride && h->t_nr == n_rows && h->t_fov == h->cam.fov;
+                        h->t_rs == row_stride && h->t_blk == row_block && h->t_nr == n_rows && h->t_fov == h->cam.fov;
     if (!t_same) {
-        RTX_HIP_CHECK(hipStreamSynchronize(stream));        // an earlier enqueued copy may still read h_tables
+        if (h->have_done) RTX_HIP_CHECK(hipEventSynchronize(h->ev_done));   // an earlier render's enqueued copy may still read h_tables
         if (h->h_tables_doubles < tdbl) {
             if (h->h_tables) RTX_HIP_CHECK(hipHostFree(h->h_tables));
             h->h_tables = nullptr; h->h_tables_doubles = 0;
@@ -742,12 +778,13 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             sx[x] = std::sin(angle_x); cx[x] = std::cos(angle_x);
         }
         for (uint32_t k = 0; k < n_rows; ++k) {
-            double v = (double)(row_begin + k * row_stride) / (double)height;           // scene.rs:153
+            const uint32_t kb = k / row_block;
+            double v = (double)(row_begin + kb * row_stride + (k - kb * row_block)) / (double)height;   // scene.rs:153 (image_row)
             double angle_y = vertical_fov * (v - 0.5);                                  // scene.rs:215
             sy[k] = std::sin(angle_y); cy[k] = std::cos(angle_y);
         }
         RTX_HIP_CHECK(hipMemcpyAsync(h->tables, h->h_tables, tdbl * sizeof(double), hipMemcpyHostToDevice, stream));
-        h->t_w = width; h->t_h = height; h->t_rb = row_begin; h->t_rs = row_stride; h->t_nr = n_rows;
+        h->t_w = width; h->t_h = height; h->t_rb = row_begin; h->t_rs = row_stride; h->t_blk = row_block; h->t_nr = n_rows;
         h->t_fov = fov; h->t_valid = true;
     }
 
@@ -758,16 +795,14 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (batch < spp) {
         if (int32_t rc = grow((void **)&h->acc, &h->acc_bytes, (size_t)npix * 3 * sizeof(double))) return rc;
     }
-    // a tree without triangle leaves runs the spheres kernel (f32-only loop, more waves per SIMD; RTX_HIP_BVH_CLASSIC=1: the
+    // a tree without triangle leaves runs the spheres kernel (f32-only loop, more waves per SIMD; RTX_TUNE_BVH_CLASSIC: the
     // general lock-step kernel, for A/B runs)
-    const bool spheres_kernel = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0 &&
-                                !std::getenv("RTX_HIP_BVH_CLASSIC");
+    const bool spheres_kernel = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0 && !classic;
     // the regrouping schedule on a tree with triangle leaves runs the mesh kernel (f32-only traversal step;
-    // RTX_HIP_BVH_CLASSIC=1: trace_bvh_regroup_kernel)
-    const bool mesh_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 2u) != 0u && !std::getenv("RTX_HIP_BVH_CLASSIC");
-    // the regrouping schedule on a tree without triangle leaves: the pool kernel (RTX_HIP_BVH_CLASSIC=1: round 1's)
-    const bool pool_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 3u) == 1u && h->sv.n_bvh_nodes != 0 &&
-                             !std::getenv("RTX_HIP_BVH_CLASSIC");
+    // RTX_TUNE_BVH_CLASSIC: trace_bvh_regroup_kernel)
+    const bool mesh_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 2u) != 0u && !classic;
+    // the regrouping schedule on a tree without triangle leaves: the pool kernel (RTX_TUNE_BVH_CLASSIC: round 1's)
+    const bool pool_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 3u) == 1u && h->sv.n_bvh_nodes != 0 && !classic;
     if (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) {
         const size_t need = pool_kernel ? bvh_spheres_pool_bytes(h->sv, h->n_cus)
                             : spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus)
@@ -777,9 +812,9 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
-    // the sphere kernel's two-stage form from 2^20 rays per launch on (RTX_HIP_BVH_ONE_STAGE=1: one launch, for A/B runs)
-    const bool spheres_two_stage = spheres_kernel && batch * per_sample64 >= (1ull << 20) && h->cfg.max_bounces > 0 &&
-                                   !std::getenv("RTX_HIP_BVH_ONE_STAGE");
+    // the sphere kernel's two-stage form from 2^20 rays per launch on (RTX_TUNE_ONE_STAGE: one launch, for A/B runs)
+    const bool spheres_two_stage = spheres_kernel && h->cfg.max_bounces > 0 && (tuning & RTX_TUNE_ONE_STAGE) == 0u &&
+                                   (batch * per_sample64 >= (1ull << 20) || (tuning & RTX_TUNE_TWO_STAGE) != 0u);
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
     }
@@ -791,7 +826,7 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
     RowsView rv{};
     rv.width = width; rv.height = height;
-    rv.row_begin = row_begin; rv.row_stride = row_stride; rv.n_rows = n_rows;
+    rv.row_begin = row_begin; rv.row_stride = row_stride; rv.n_rows = n_rows; rv.row_block = row_block;
     rv.npix = npix;
     rv.sin_x = h->tables; rv.cos_x = h->tables + width;
     rv.sin_y = h->tables + 2 * (size_t)width; rv.cos_y = rv.sin_y + n_rows;
@@ -846,7 +881,8 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             if (spheres_kernel)
                 RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus,
-                                                       spheres_two_stage ? h->wf_state : nullptr, stream));
+                                                       spheres_two_stage ? h->wf_state : nullptr,
+                                                       (tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u, stream));
             else
                 RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
@@ -867,15 +903,18 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
             trace_ms += a; resolve_ms += b;
         }
     }
-    if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
-        // round-bound watchdog of the sweep kernel (ctr[1].pad_, sticky within this call): mirrored to a pinned word
-        // and looked at by the next entry point that finds the copy complete, whether or not stats were asked for
+    if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY || spheres_two_stage) {
+        // the launch's watchdog word (ctr[1].pad_, sticky within this call: the sweep kernel's round bound, a survivor the
+        // sphere kernel's queue could not take): mirrored to a pinned word and looked at by the next entry point that finds
+        // the copy complete, whether or not stats were asked for
         if (h->watchdog_pending) RTX_HIP_CHECK(hipEventSynchronize(h->ev_watchdog));
         if (int32_t rc = check_watchdog(h, false)) return rc;
         RTX_HIP_CHECK(hipMemcpyAsync(h->h_watchdog, &h->counters[1].pad_, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         RTX_HIP_CHECK(hipEventRecord(h->ev_watchdog, stream));
         h->watchdog_pending = true;
     }
+    RTX_HIP_CHECK(hipEventRecord(h->ev_done, stream));      // what a later call on another stream waits for (adopt_stream)
+    h->have_done = true;
     if (stats) {
         RTX_HIP_CHECK(hipStreamSynchronize(stream));
         Counters host[kCounterShards];
@@ -889,8 +928,8 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         for (int k = 2; k < kCounterShards; ++k) stats->box_tests += host[k].pad_;
         if (host[1].pad_ != 0) {
             h->watchdog_pending = false; *h->h_watchdog = 0ull;        // reported right here
-            return fail(RTX_ERR_HIP, "trace kernel hit its round bound (internal error): " + std::to_string(host[1].pad_) +
-                                         " workgroup(s) left early");
+            return fail(RTX_ERR_HIP, "trace kernel raised its watchdog word (internal error: round bound / full survivors' queue): " +
+                                         std::to_string(host[1].pad_) + " event(s)");
         }
         stats->primary_rays = (uint64_t)npix * spp;
         stats->trace_ms = trace_ms;
@@ -899,6 +938,35 @@ int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
         stats->kernel = kernel;                       // the kernel that actually ran (RTX_KERNEL_*)
     }
     return RTX_OK;
+}
+
+extern "C" {
+
+int32_t rtx_render_rows(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_stride,
+                        uint32_t n_rows, double *d_out_rgb, void *stream, RtxStats *stats)
+{
+    if (!h) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: null scene");
+    if (n_rows != 0 && width != 0) {
+        if (row_stride == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: row_stride == 0");
+        if ((uint64_t)row_begin + (uint64_t)(n_rows - 1) * row_stride >= height)
+            return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_rows: rows exceed the image height");
+    }
+    return render_band(h, width, height, row_begin, row_stride, 1u, n_rows, d_out_rgb, stream, stats);
+}
+
+uint32_t rtx_blocks_row_count(uint32_t height, uint32_t block_rows, uint32_t part, uint32_t n_parts)
+{
+    return blocks_row_count(height, block_rows, part, n_parts);
+}
+
+int32_t rtx_render_blocks(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t block_rows, uint32_t part, uint32_t n_parts,
+                          double *d_out_rgb, void *stream, RtxStats *stats)
+{
+    if (!h) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_blocks: null scene");
+    if (block_rows == 0 || n_parts == 0 || part >= n_parts) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_blocks: bad partition");
+    if ((uint64_t)block_rows * n_parts > 0xFFFFFFF0ull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render_blocks: block_rows * n_parts overflows");
+    const uint32_t n_rows = blocks_row_count(height, block_rows, part, n_parts);
+    return render_band(h, width, height, part * block_rows, n_parts * block_rows, block_rows, n_rows, d_out_rgb, stream, stats);
 }
 
 int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t height, uint8_t *d_rgb8, int32_t device,
@@ -913,17 +981,22 @@ int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t 
 
 // Scene::render / render_to_image over a list of devices (one entry = rtx_render's single-GPU form).
 //
-// The frame is partitioned into interleaved row bands (device k of n renders rows y = k, k + n, ...: interleaving
-// balances the uneven per-pixel cost), the scene is packed ONCE on the host and replicated, one host thread per
-// device uploads, renders its band (rtx_render_rows, asynchronously on the thread's own stream) and hands the band to
-// the staging buffer on devices[0]; then one de-interleave kernel (+ the u8 epilogue) and ONE device-to-host copy.
-// There is no exchange during the render (pixels are independent, scene.rs:149-160).
+// The frame is cut into blocks of kRowBlock = 8 rows dealt out round-robin (device k of n renders blocks k, k + n, ...:
+// interleaving balances the uneven per-pixel cost, and 8 rows keep the BVH kernels' 8x8 ray tiles whole -- with single
+// interleaved rows a "tile" of device k was 8 columns x 8n image rows, which cost the packet walks a quarter to a third of
+// their rate), the scene is packed ONCE on the host and replicated, one host thread per device uploads, renders its band
+// (asynchronously on the thread's own stream), for render_to_image quantises it there (3 bytes per pixel travel instead of
+// 24) and hands it to the staging buffer on devices[0]; then one de-interleave kernel (with the image's vertical flip in
+// the u8 form) and ONE device-to-host copy.  There is no exchange during the render (pixels are independent,
+// scene.rs:149-160).
 //
 // The gather is hipMemcpyPeerAsync, not RCCL: inside one process the bands are n - 1 independent point-to-point
 // copies into disjoint regions of one buffer -- each peer's DMA engine pushes over its own xGMI link to devices[0], which
 // is what a gather does on this topology -- and a peer copy needs no communicator (ncclCommInitAll costs more than a
 // C2 frame) and accepts a device list with repeated entries, which is how the path is tested on a one-GPU box.  The
 // process-per-GPU form of the same partition (bench.py, rust-raytracing_amd/tiles.py) gathers with RCCL.
+constexpr uint32_t kRowBlock = 8;
+
 static int32_t render_common(const RtxScene *scene, uint32_t width, uint32_t height, const int32_t *devices, uint32_t n_dev,
                              double *out_rgb, uint8_t *out_rgb8)
 {
@@ -939,53 +1012,63 @@ static int32_t render_common(const RtxScene *scene, uint32_t width, uint32_t hei
     if (int32_t rc = pack_scene(scene, packed)) return rc;
 
     const int dev0 = devices[0];
-    const uint32_t cap_rows = (height + n_dev - 1) / n_dev;                   // rows of the largest band
-    const size_t band_doubles = (size_t)cap_rows * width * 3;
-    double *d_parts = nullptr, *d_full = nullptr;
-    uint8_t *d_q = nullptr;
+    const uint32_t cap_rows = blocks_row_count(height, kRowBlock, 0, n_dev);   // rows of the largest band (part 0's)
+    const size_t band_vals = (size_t)cap_rows * width * 3;
+    const bool as_u8 = out_rgb == nullptr;             // render_to_image: the bands travel as bytes
+    const size_t val_bytes = as_u8 ? 1 : sizeof(double);
+    char *d_parts = nullptr, *d_full = nullptr;        // staging on devices[0]: n bands; the assembled frame
     RTX_HIP_CHECK(hipSetDevice(dev0));
-    hipError_t e = hipMalloc((void **)&d_parts, band_doubles * n_dev * sizeof(double));
-    if (e == hipSuccess && n_dev > 1) e = hipMalloc((void **)&d_full, npix * 3 * sizeof(double));
-    if (e == hipSuccess && out_rgb8) e = hipMalloc((void **)&d_q, npix * 3);
+    hipError_t e = hipMalloc((void **)&d_parts, band_vals * n_dev * val_bytes);
+    if (e == hipSuccess && (n_dev > 1 || as_u8)) e = hipMalloc((void **)&d_full, npix * 3 * val_bytes);
     int32_t rc = RTX_OK;
     if (e != hipSuccess) rc = fail(RTX_ERR_OUT_OF_MEMORY, std::string("rtx_render: ") + hipGetErrorString(e));
 
     struct Worker { int32_t rc = RTX_OK; std::string msg; };
     std::vector<Worker> res(n_dev);
-    const bool dbg = std::getenv("RTX_HIP_DEBUG") != nullptr;
+    const bool dbg = debug_prints();
     auto work = [&](uint32_t k) {
         Worker &w = res[k];
         const int dev = devices[k];
         RtxSceneHandle_ *h = nullptr;
         hipStream_t stream = nullptr;
-        double *d_band = nullptr;
-        const uint32_t n_rows = k < height ? (height - k + n_dev - 1) / n_dev : 0u;
+        double *d_band = nullptr;                                       // f64 band on this device
+        uint8_t *d_band8 = nullptr;                                     // its u8 form (render_to_image)
+        const uint32_t n_rows = blocks_row_count(height, kRowBlock, k, n_dev);
+        const size_t n_vals = (size_t)n_rows * width * 3;
         auto step = [&](int32_t r) { if (r && !w.rc) { w.rc = r; w.msg = g_last_error; } return w.rc == RTX_OK; };
         auto hip = [&](hipError_t he, const char *what) {
             if (he != hipSuccess && !w.rc) { w.rc = he == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP; w.msg = std::string(what) + ": " + hipGetErrorString(he); }
             return w.rc == RTX_OK;
         };
         if (step(create_handle(scene, packed, dev, &h)) && hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate")) {
-            double *dst = d_parts + (size_t)k * band_doubles;           // this band's region of the staging buffer on devices[0]
-            if (dev == dev0) d_band = dst;                              // render straight into it
-            else {
+            char *dst = d_parts + (size_t)k * band_vals * val_bytes;    // this band's region of the staging buffer on devices[0]
+            const bool local = dev == dev0;
+            if (!local) {
                 int can = 0;                                            // direct xGMI DMA when the pair allows it (else the copy is staged)
                 if (hipDeviceCanAccessPeer(&can, dev, dev0) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(dev0, 0);
                 (void)hipGetLastError();                                // "already enabled" is not an error
-                hip(hipMalloc((void **)&d_band, band_doubles * sizeof(double)), "hipMalloc(band)");
+            }
+            if (local && !as_u8) d_band = reinterpret_cast<double *>(dst);   // render straight into the staging buffer
+            else hip(hipMalloc((void **)&d_band, band_vals * sizeof(double)), "hipMalloc(band)");
+            if (as_u8) {
+                if (local) d_band8 = reinterpret_cast<uint8_t *>(dst);
+                else hip(hipMalloc((void **)&d_band8, band_vals), "hipMalloc(band8)");
             }
             RtxStats st;
-            if (w.rc == RTX_OK && n_rows) step(rtx_render_rows(h, width, height, k, n_dev, n_rows, d_band, stream, dbg ? &st : nullptr));
+            if (w.rc == RTX_OK && n_rows) step(rtx_render_blocks(h, width, height, kRowBlock, k, n_dev, d_band, stream, dbg ? &st : nullptr));
             if (w.rc == RTX_OK && n_rows && dbg)
                 std::fprintf(stderr, "[rtx_hip] device %d band %u/%u: rays %llu segments %llu exact %llu filter %llu mismatches %llu trace %.3f ms resolve %.3f ms\n",
                              dev, k, n_dev, (unsigned long long)st.primary_rays, (unsigned long long)st.segments, (unsigned long long)st.exact_tests,
                              (unsigned long long)st.filter_tests, (unsigned long long)st.filter_mismatches, st.trace_ms, st.resolve_ms);
-            if (w.rc == RTX_OK && n_rows && dev != dev0)
-                hip(hipMemcpyPeerAsync(dst, dev0, d_band, dev, (size_t)n_rows * width * 3 * sizeof(double), stream), "hipMemcpyPeerAsync");
+            if (w.rc == RTX_OK && n_rows && as_u8) hip(launch_quantize_values(d_band, d_band8, n_vals, stream), "quantize_values_kernel");
+            if (w.rc == RTX_OK && n_rows && !local)
+                hip(hipMemcpyPeerAsync(dst, dev0, as_u8 ? (const void *)d_band8 : (const void *)d_band, dev, n_vals * val_bytes, stream),
+                    "hipMemcpyPeerAsync");
             if (stream) hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
         }
-        if (h) step(rtx_scene_free(h));                                 // (reports the sweep kernel's watchdog)
-        if (d_band && dev != dev0) (void)hipFree(d_band);
+        if (h) step(rtx_scene_free(h));                                 // (reports the launch's watchdog word)
+        if (d_band && !(dev == dev0 && !as_u8)) (void)hipFree(d_band);
+        if (d_band8 && dev != dev0) (void)hipFree(d_band8);
         if (stream) (void)hipStreamDestroy(stream);
     };
     if (!rc) {
@@ -1000,18 +1083,23 @@ static int32_t render_common(const RtxScene *scene, uint32_t width, uint32_t hei
     }
     if (!rc) {
         e = hipSetDevice(dev0);
-        const double *d_img = d_parts;                                  // one device: the band IS the frame
-        if (e == hipSuccess && n_dev > 1) { e = launch_deinterleave(d_parts, d_full, width, height, n_dev, cap_rows, nullptr); d_img = d_full; }
-        if (e == hipSuccess && out_rgb8) e = launch_quantize(d_img, d_q, width, height, nullptr);
+        const char *d_img = d_parts;                                    // one device, f64: the band IS the frame
+        if (e == hipSuccess && as_u8) {
+            e = launch_deinterleave_u8(reinterpret_cast<const uint8_t *>(d_parts), reinterpret_cast<uint8_t *>(d_full), width, height,
+                                       n_dev, cap_rows, kRowBlock, true, nullptr);      // + the flip of scene.rs:176
+            d_img = d_full;
+        } else if (e == hipSuccess && n_dev > 1) {
+            e = launch_deinterleave(reinterpret_cast<const double *>(d_parts), reinterpret_cast<double *>(d_full), width, height, n_dev,
+                                    cap_rows, kRowBlock, nullptr);
+            d_img = d_full;
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess && out_rgb) e = hipMemcpy(out_rgb, d_img, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && out_rgb8) e = hipMemcpy(out_rgb8, d_q, npix * 3, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(as_u8 ? (void *)out_rgb8 : (void *)out_rgb, d_img, npix * 3 * val_bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RTX_ERR_HIP, std::string("rtx_render: ") + hipGetErrorString(e));
     }
     (void)hipSetDevice(dev0);
     if (d_parts) (void)hipFree(d_parts);
     if (d_full) (void)hipFree(d_full);
-    if (d_q) (void)hipFree(d_q);
     return rc;
 }
 

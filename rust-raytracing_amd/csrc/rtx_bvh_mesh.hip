@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                         if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                         else ray_index_to_pixel(rv, ridx, pl, smp);
                         const uint32_t k = pl / rv.width, x = pl - k * rv.width;
-                        const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                        const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                         r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                         r.bounce = 1u;
                         r.draw = 8u;
@@ -368,8 +368,8 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     // generating its own rays 16 stays (C5 band alone: 96 ms at 16, 108 at 32), and so it does for a joint tree (240k axis-aligned
     // faces from the queue: 222 ms at 16, 233 at 32)
     const uint32_t thresh = [&] {
-        const char *e = std::getenv("RTX_HIP_BVH_THRESH");
-        long v = e && *e ? std::strtol(e, nullptr, 10) : (src && (sv.bvh_flags & 4u) != 0u ? 2 * RTX_BVH_MESH_THRESH : RTX_BVH_MESH_THRESH);
+        const uint32_t t = (sv.tuning >> RTX_TUNE_THRESH_SHIFT) & 127u;
+        long v = t ? (long)t : (src && (sv.bvh_flags & 4u) != 0u ? 2 * RTX_BVH_MESH_THRESH : RTX_BVH_MESH_THRESH);
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     LeafArrays la;
@@ -379,8 +379,8 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     ma.sphere_cr = sv.bvh_leaf_cr; ma.sphere_prims = sv.bvh_prims; ma.tri_f32 = sv.tri_f32; ma.tri_geo = sv.tri_geo;
     const uint32_t need_stack = 3u * sv.bvh_depth + 2u, lds_stack = (uint32_t)(wide ? kMeshStackQ : kMeshStack);
     const uint32_t spill_entries = spill && need_stack > lds_stack ? need_stack - lds_stack : 0u;
-    // 0: a joint tree; 1: nothing but (x, y)-footprint triangles; 2: ... with the 64-byte nodes (RTX_HIP_NO_QNODES=1: A/B runs)
-    const bool no_q = std::getenv("RTX_HIP_NO_QNODES") != nullptr;
+    // 0: a joint tree; 1: nothing but (x, y)-footprint triangles; 2: ... with the 64-byte nodes (RTX_TUNE_NO_QNODES: A/B runs)
+    const bool no_q = (sv.tuning & RTX_TUNE_NO_QNODES) != 0u;
     const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : ((sv.bvh_flags & 8u) != 0u && !no_q ? 2 : 1);
     void (*kernel)(const SceneView *, const RowsView *, double *, Counters *, unsigned long long *, const float4 *, const LeafArrays,
                    const MeshArrays, uint32_t *, uint32_t, uint32_t, const MeshRaySource) = nullptr;

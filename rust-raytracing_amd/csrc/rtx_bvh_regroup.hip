@@ -233,9 +233,9 @@ hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, 
     const uint64_t cap = (uint64_t)n_cus * kBvhWavesPerSimd;
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
-    const uint32_t thresh = [] {                         // tuning knob
-        const char *e = std::getenv("RTX_HIP_BVH_THRESH");
-        long v = e && *e ? std::strtol(e, nullptr, 10) : RTX_BVH_THRESH;
+    const uint32_t thresh = [&] {                        // tuning knob
+        const uint32_t t = (sv.tuning >> RTX_TUNE_THRESH_SHIFT) & 127u;
+        long v = t ? (long)t : RTX_BVH_THRESH;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     LeafArrays la;

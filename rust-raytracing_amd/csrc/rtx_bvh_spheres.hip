@@ -28,14 +28,65 @@ constexpr int kSphStack = 30;                // LDS stack entries per lane: (30 
 //            queue (state structure-of-arrays by slot; a wave reserves 512 slots per atomic and marks what it leaves
 //            unused as dead)
 //   MODE 2   the same kernel fed from that queue: every lane carries a bounced ray, idle lanes take the next ones
-// MODE 0 is the single launch (small launches, A/B runs: RTX_HIP_BVH_ONE_STAGE=1).
+// MODE 0 is the single launch (small launches, A/B runs: RTX_TUNE_ONE_STAGE).
+// A survivor is what a ray is after its FIRST hit: position, new direction, its index in the launch's queue and the object
+// it hit -- ray.resulting_color / light_color are then exactly that object's emission / base colour folded into (0,0,0) /
+// (1,1,1) (scene.rs:276-277), which stage 2 recomputes with the same two operations.  One 64-byte record per survivor,
+// written and read whole (four 16-byte accesses per lane, a wave's records contiguous).
+struct SphSurvivor {
+    double px, py, pz, dx, dy, dz;
+    uint32_t ridx;                            // kNone: a slot its wave reserved and did not use
+    uint32_t first_id;                        // scene index of the object of the first hit
+    uint32_t pad_[2];
+};
+static_assert(sizeof(SphSurvivor) == 64, "SphSurvivor must be one 64-byte line");
 struct SphQueue {
-    double *pos[3], *dir[3], *res[3], *lig[3];
-    uint32_t *ridx;                           // kNone: a slot its wave reserved and did not use
+    SphSurvivor *rec;
     unsigned long long *count;                // slots reserved by stage 1 = the length stage 2 walks
     unsigned long long capacity;
 };
 constexpr uint32_t kSphQueueChunk = 512;
+
+// Appends the wave's survivors (lanes with `go`) to the queue: consecutive slots of the wave's current reservation; when it
+// runs out mid-way the rest continue in a fresh chunk (one atomic per 512 records), so no slot is wasted except the tail of
+// a wave's LAST chunk, which the kernel marks dead before it leaves.  A slot beyond the capacity (the host sizes the queue
+// so that it cannot happen: n_rays + one chunk per wave) raises the launch's watchdog word instead of being dropped silently.
+__device__ __forceinline__ void sph_queue_append(const SphQueue &sq, Counters *__restrict__ ctr, bool go, const RayState &r,
+                                                 uint32_t ridx, uint32_t first_id, uint32_t lane,
+                                                 unsigned long long &out_next, unsigned long long &out_end)
+{
+    const unsigned long long m = __ballot(go);
+    const uint32_t n = (uint32_t)__popcll(m);
+    if (n == 0u) return;
+    const unsigned long long rem = out_end - out_next;
+    unsigned long long base2 = 0;
+    if (rem < (unsigned long long)n) {
+        if (lane == 0) base2 = atomicAdd(sq.count, (unsigned long long)kSphQueueChunk);
+        base2 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base2 >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)base2);
+    }
+    if (go) {
+        const unsigned long long k = bvh_mbcnt(m);
+        const unsigned long long slot = k < rem ? out_next + k : base2 + (k - rem);
+        if (slot < sq.capacity) {
+            double4 *p = reinterpret_cast<double4 *>(sq.rec + slot);
+            p[0] = make_double4(r.pos.x, r.pos.y, r.pos.z, r.dir.x);
+            uint2 tail;
+            tail.x = ridx; tail.y = first_id;
+            p[1] = make_double4(r.dir.y, r.dir.z, __longlong_as_double(((long long)tail.y << 32) | (long long)tail.x), 0.0);
+        } else {
+            atomicAdd(&ctr[1].pad_, 1ull);
+        }
+    }
+    if (rem < (unsigned long long)n) { out_next = base2 + ((unsigned long long)n - rem); out_end = base2 + kSphQueueChunk; }
+    else out_next += n;
+}
+
+__device__ __forceinline__ void sph_queue_close(const SphQueue &sq, uint32_t lane, unsigned long long out_next, unsigned long long out_end)
+{
+    for (unsigned long long s = out_next + lane; s < out_end; s += 64ull)
+        if (s < sq.capacity) sq.rec[s].ridx = kNone;
+}
 
 template <bool SPILL, int MODE>
 __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spheres_kernel(const SceneView *__restrict__ svp,
@@ -64,6 +115,7 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
     bool alive = false;
     RayState r;
     uint32_t ridx = 0;                       // the ray's index in the launch's queue = where its sample goes
+    uint32_t first_id = 0;                   // MODE 1: the object of the first hit
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
 
     for (;;) {
@@ -84,22 +136,27 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                 bool valid = my < wave_end;
                 uint32_t pl = 0, smp = 0;
                 if constexpr (MODE == 2) {
+                    double4 s0 = make_double4(0., 0., 0., 0.), s1 = s0;
                     if (valid) {                           // a ray in flight, as stage 1 left it after its first hit
-                        ridx = sq.ridx[my];
+                        const double4 *p = reinterpret_cast<const double4 *>(sq.rec + my);
+                        s0 = p[0]; s1 = p[1];
+                        ridx = (uint32_t)(unsigned long long)__double_as_longlong(s1.z);
                         valid = ridx != kNone;
                     }
                     if (valid) {
                         if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                         else ray_index_to_pixel(rv, ridx, pl, smp);
                         const uint32_t k = pl / rv.width, x = pl - k * rv.width;
-                        const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                        const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                         r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                         r.bounce = 1u;
                         r.draw = 8u;
-                        r.pos = mk(sq.pos[0][my], sq.pos[1][my], sq.pos[2][my]);
-                        r.dir = mk(sq.dir[0][my], sq.dir[1][my], sq.dir[2][my]);
-                        r.result = mk(sq.res[0][my], sq.res[1][my], sq.res[2][my]);
-                        r.light = mk(sq.lig[0][my], sq.lig[1][my], sq.lig[2][my]);
+                        r.pos = mk(s0.x, s0.y, s0.z);
+                        r.dir = mk(s0.w, s1.x, s1.y);
+                        // ray_hit's two folds of the first hit (scene.rs:276-277) from resulting_color = 0, light_color = 1 (ray.rs:18-19)
+                        const MaterialX m = sv.materials[(uint32_t)((unsigned long long)__double_as_longlong(s1.z) >> 32)];
+                        r.result = vadd(mk(0.0, 0.0, 0.0), vmulv(mk(1.0, 1.0, 1.0), m.emission_color));
+                        r.light = vmulv(mk(1.0, 1.0, 1.0), m.base_color);
                         alive = true;
                     }
                 } else {
@@ -193,6 +250,7 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
             bool done = true;
             if (h.id != kNone) {
                 advance_and_shade(sv, h, r);
+                first_id = h.id;
                 done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
             }
             if (done) {
@@ -202,39 +260,11 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
         }
         if constexpr (MODE == 1) {
             // ---- the survivors of this round move to the queue of rays in flight; every lane is free again
-            const bool go = alive;
-            const unsigned long long m = __ballot(go);
-            const uint32_t n = (uint32_t)__popcll(m);
-            if (n != 0u) {
-                if (out_end - out_next < (unsigned long long)n) {
-                    // what is left of the wave's reservation does not take them: mark it unused, reserve the next chunk
-                    if (out_next + lane < out_end) sq.ridx[out_next + lane] = kNone;       // (fewer than 64 slots are left)
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(sq.count, (unsigned long long)kSphQueueChunk);
-                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
-                           __builtin_amdgcn_readfirstlane((uint32_t)base);
-                    out_next = base;
-                    out_end = base + kSphQueueChunk;
-                }
-                if (go) {
-                    const unsigned long long slot = out_next + bvh_mbcnt(m);
-                    if (slot < sq.capacity) {                  // (the host sizes the queue so that this always holds)
-                        sq.pos[0][slot] = r.pos.x; sq.pos[1][slot] = r.pos.y; sq.pos[2][slot] = r.pos.z;
-                        sq.dir[0][slot] = r.dir.x; sq.dir[1][slot] = r.dir.y; sq.dir[2][slot] = r.dir.z;
-                        sq.res[0][slot] = r.result.x; sq.res[1][slot] = r.result.y; sq.res[2][slot] = r.result.z;
-                        sq.lig[0][slot] = r.light.x; sq.lig[1][slot] = r.light.y; sq.lig[2][slot] = r.light.z;
-                        sq.ridx[slot] = ridx;
-                    }
-                }
-                out_next += n;
-            }
+            sph_queue_append(sq, ctr, alive, r, ridx, first_id, lane, out_next, out_end);
             alive = false;
         }
     }
-    if constexpr (MODE == 1) {                    // the unused rest of the wave's last reservation
-        for (unsigned long long s = out_next + lane; s < out_end; s += 64ull)
-            if (s < sq.capacity) sq.ridx[s] = kNone;
-    }
+    if constexpr (MODE == 1) sph_queue_close(sq, lane, out_next, out_end);      // the unused rest of the wave's last reservation
     // counters: segments, exact f64 shape tests, box tests + leaf filter tests (reported through filter_tests)
     unsigned long long filt = box_tests + leaf_filters;
 #pragma unroll
@@ -253,6 +283,320 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
     }
 }
 
+// ---- stage 1 as packets -----------------------------------------------------------------------------------------------------
+// The primary rays of an 8x8 pixel tile leave (almost) one point in directions a few pixels apart: at the far side of C2's
+// cloud they are less than a unit apart, a fraction of the spacing of the spheres.  So the wave walks the tree ONCE for the
+// 64 of them (the move that took C3's level 0 from 62.9 to 29.0 ms, rtx_wavefront.hip): a wave-uniform stack, the node and
+// the leaf's {c - centre, r} record read at a wave-uniform address through the scalar cache, every lane testing ITS ray
+// against the four boxes with ITS bound and bounding the leaf's sphere with sphere_step's closest-approach terms.  A child
+// is opened when any lane's ray enters it, in the first entering lane's order.  What a lane collects is what its own walk
+// collects for SOME visiting order -- every candidate with t_lo <= its best_up -- and the exact tests (sphere.rs:19-30)
+// decide as always: bit-identical.  Around the walk the wave runs render_pixel's prologue, the exact tests and ray_hit
+// with all 64 lanes (no lane waits for a longer walk), and the survivors go to stage 2's queue.
+//
+// When all rays of the tile point into the same octant (every tile but those on the image's centre row / column) the
+// near and far plane of each slab are picked with scalar selects and the slab test is 6 FMAs + max3 / min3 instead of
+// 6 FMAs + 12 min / max: same values (the FMA is monotone in the plane), fewer VALU instructions.
+constexpr int kSpkStack = 63;                // wave-uniform stack entries: the lanes of ONE VGPR (the host checks 3 * depth + 2 against it)
+#ifndef RTX_SPK_WAVES
+#define RTX_SPK_WAVES 4
+#endif
+constexpr int kSpkWaves = RTX_SPK_WAVES;     // workgroups per CU
+constexpr uint32_t kSphNoPackets = 1u;       // launch flag: stage 1 per lane (A/B runs)
+
+// The walk of one tile.  SGN < 8: every ray of the tile points into octant SGN (bit a set: direction component a is
+// negative), so the near / far plane of each slab is known at compile time; SGN == 8: mixed signs, min / max per slab.
+//
+// Where the time goes decides the shape of this loop.  The first version (profiles/r03_sph_packets_v1.txt) issued 44 %
+// fewer VALU instructions than the per-lane walk and was only 16 % faster: it had become SCALAR-bound -- 9.6e9 SALU
+// instructions per launch against 7.7e9 VALU, and a CU has one scalar pipe for its four SIMDs (74 % busy) -- on the
+// uniform near / far selects (48 s_and + s_cselect per visit), the exec-masked lane-0 stores of the LDS stack, and
+// branches around every child.  Now: the selects are resolved at compile time (one instance of the loop per octant), the
+// stack lives in the lanes of one VGPR (v_writelane / v_readlane with a scalar index: no LDS, no exec masking, three
+// unconditional pushes), the hit masks of the box tests are kept as they come out of v_cmp and reused for the ordering
+// keys, and the leaf code exists once.
+// v_writelane_b32 (this clang has no __builtin_amdgcn_writelane; the LLVM intrinsic is reached by its name)
+extern "C" __device__ int rtx_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+template <int SGN>
+__device__ __forceinline__ void sph_packet_walk(const PkConst4 cnodes, const PkConst4 csph, const PkConstU32 cprims, uint32_t root,
+                                                const Ray32S &q, const SphereRay &sr, uint32_t *lq, uint32_t tid, uint32_t lane,
+                                                float &best_up, uint32_t &qcnt, bool &overflow, uint32_t &nbox, uint32_t &nleaf)
+{
+    int stk = 0;                                                       // lane k = stack entry k
+    uint32_t sp = 0, node = __builtin_amdgcn_readfirstlane(root);
+    while (node != kNone) {
+        // the node's 128 bytes at a wave-uniform address: 4 x {lo.xyz, link}, 4 x {hi.xyz, count}
+        const PkConst4 np = cnodes + 8 * (size_t)node;
+        float4 a[4], b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] = np[c]; b[c] = np[4 + c]; }
+        uint32_t lnk[4], cnt[4];
+        float tc[4];
+        unsigned long long hm[4];                                      // lanes whose ray enters child c
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lnk[c] = pk_bits(a[c].w);
+            cnt[c] = pk_bits(b[c].w);
+            float tn, tf;
+            if (SGN < 8) {
+                const float nx_ = (SGN & 1) ? b[c].x : a[c].x, fx_ = (SGN & 1) ? a[c].x : b[c].x;
+                const float ny_ = (SGN & 2) ? b[c].y : a[c].y, fy_ = (SGN & 2) ? a[c].y : b[c].y;
+                const float nz_ = (SGN & 4) ? b[c].z : a[c].z, fz_ = (SGN & 4) ? a[c].z : b[c].z;
+                tn = fmaxf(fmaxf(__builtin_fmaf(nx_, q.ix, q.nx), __builtin_fmaf(ny_, q.iy, q.ny)), fmaxf(__builtin_fmaf(nz_, q.iz, q.nz), 0.0f));
+                tf = fminf(fminf(__builtin_fmaf(fx_, q.ix, q.nx), __builtin_fmaf(fy_, q.iy, q.ny)), __builtin_fmaf(fz_, q.iz, q.nz));
+            } else {
+                const float x0 = __builtin_fmaf(a[c].x, q.ix, q.nx), x1 = __builtin_fmaf(b[c].x, q.ix, q.nx);
+                const float y0 = __builtin_fmaf(a[c].y, q.iy, q.ny), y1 = __builtin_fmaf(b[c].y, q.iy, q.ny);
+                const float z0 = __builtin_fmaf(a[c].z, q.iz, q.nz), z1 = __builtin_fmaf(b[c].z, q.iz, q.nz);
+                tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+                tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            }
+            // box_entry32's widening (rtx_traverse.h): (1 -+ 2^-21) and the slack of a far origin
+            tc[c] = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -q.e);
+            const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, q.e);
+            hm[c] = __builtin_amdgcn_ballot_w64(tc[c] <= fminf(tf_hi, best_up));   // (one compare: the mask comes straight out of v_cmp;
+                                                                                    //  an empty slot's box is inverted: never entered)
+        }
+        if (best_up >= 0.0f) nbox += 4;
+        // leaves first: their certain hits tighten the bound the interior children are then held against
+        if (((cnt[0] | cnt[1] | cnt[2] | cnt[3]) & 0xFFFFu) != 0u) {       // some child is a leaf (or an empty slot: never entered)
+            uint32_t leafmask = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (cnt[c] - 1u < 0xFFFFu && hm[c] != 0ull) leafmask |= 1u << c;             // wave-uniform
+            while (leafmask != 0u) {
+                const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
+                leafmask &= leafmask - 1u;
+                const uint32_t first = c == 0 ? lnk[0] : (c == 1 ? lnk[1] : (c == 2 ? lnk[2] : lnk[3]));
+                const uint32_t n = (c == 0 ? cnt[0] : (c == 1 ? cnt[1] : (c == 2 ? cnt[2] : cnt[3]))) & 0xFFFFu;
+                const unsigned long long m = c == 0 ? hm[0] : (c == 1 ? hm[1] : (c == 2 ? hm[2] : hm[3]));
+                const bool in = ((m >> lane) & 1ull) != 0ull;
+                if (in) nleaf += n;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const float4 rec = csph[first + j];                    // {c - centre, r}
+                    const uint32_t prim = cprims[first + j];
+                    if (!in) continue;
+                    const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+                    const float bq = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+                    const float lx = __builtin_fmaf(-bq, sr.dx, ox), ly = __builtin_fmaf(-bq, sr.dy, oy), lz = __builtin_fmaf(-bq, sr.dz, oz);
+                    const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+                    const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+                    const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+                    const float Dp = Dl + G;
+                    if (Dp >= 0.0f) {                                      // the exact test cannot be excluded (rtx_traverse.h, sphere_step)
+                        const float tlo = bq - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+                        const float Dm = Dl - G;
+                        const float thi = Dm > 0.0f ? bq - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+                        if (tlo <= best_up && !(thi < 0.0f)) {
+                            if (tlo > sr.K) best_up = fminf(best_up, thi);
+                            if (qcnt == (uint32_t)kSphQueue) {             // drop the entries a later certain hit has overtaken
+                                uint32_t w = 0;
+#pragma unroll
+                                for (int e = 0; e < kSphQueue; ++e) {
+                                    const uint32_t ie = lq[(size_t)e * kBvhThreads + tid];
+                                    const uint32_t te = lq[(size_t)(kSphQueue + e) * kBvhThreads + tid];
+                                    if (__uint_as_float(te) <= best_up) {
+                                        lq[(size_t)w * kBvhThreads + tid] = ie;
+                                        lq[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                                        w += 1;
+                                    }
+                                }
+                                qcnt = w;
+                            }
+                            if (qcnt == (uint32_t)kSphQueue) overflow = true;   // (the segment then tests every sphere exactly)
+                            else {
+                                lq[(size_t)qcnt * kBvhThreads + tid] = prim;
+                                lq[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                                qcnt += 1;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hm[c] &= __builtin_amdgcn_ballot_w64(tc[c] <= best_up);   // the bound may have tightened
+        }
+        // interior children any lane still enters, nearest first by the first entering lane's distance (wave-uniform
+        // integer keys -- the bits of a non-negative float order like the float; a far origin's slack can make a bound
+        // negative: as a signed integer it still sorts in front --: scalar code); the farther ones are pushed
+        int key[4];
+        uint32_t kl[4];
+        constexpr int kFar = 0x7F800000;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned long long m = cnt[c] == 0u ? hm[c] : 0ull;
+            const int k = (int)__builtin_amdgcn_readlane(__float_as_uint(tc[c]), (int)__builtin_ctzll(m | 0x8000000000000000ull));
+            key[c] = m != 0ull ? k : kFar;
+            kl[c] = lnk[c];
+        }
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { int tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = kl[i]; kl[i] = kl[j]; kl[j] = tl; } }
+        RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+        // three unconditional pushes, farthest first; an invalid one lands on the slot the next push (or a later one)
+        // overwrites (sp <= 3 * depth + 2 <= 63: the index stays a lane of the register)
+        stk = rtx_writelane((int)kl[3], (int)sp, stk); sp += key[3] < kFar ? 1u : 0u;
+        stk = rtx_writelane((int)kl[2], (int)sp, stk); sp += key[2] < kFar ? 1u : 0u;
+        stk = rtx_writelane((int)kl[1], (int)sp, stk); sp += key[1] < kFar ? 1u : 0u;
+        node = key[0] < kFar ? kl[0] : kNone;
+        if (node == kNone && sp != 0u) {
+            sp -= 1;
+            node = (uint32_t)__builtin_amdgcn_readlane(stk, (int)sp);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kernel(const SceneView *__restrict__ svp,
+                                                                                  const RowsView *__restrict__ rvp,
+                                                                                  double *__restrict__ samples, Counters *__restrict__ ctr,
+                                                                                  unsigned long long *__restrict__ work_counter,
+                                                                                  const float4 *__restrict__ nodes, const LeafArrays la,
+                                                                                  const SphQueue sq)
+{
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    __shared__ uint32_t lds_q[2 * kSphQueue][kBvhThreads];
+    uint32_t *const lq = &lds_q[0][0];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
+    const unsigned long long n_rays = rv.n_rays;                        // a multiple of 64: the padded tile grid
+    const PkConst4 cnodes = pk_const(nodes), csph = pk_const(la.sphere_f32);
+    const PkConstU32 cprims = pk_const(la.sphere_prims);
+    unsigned long long wave_next = 0, wave_end = 0;                     // this wave's share of the ray queue, in rays
+    unsigned long long out_next = 0, out_end = 0;                       // its reserved slots of the survivors' queue
+    unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
+
+    for (;;) {
+        if (wave_next >= wave_end) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)rv.grab);     // (rv.grab is a multiple of 64)
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                   __builtin_amdgcn_readfirstlane((uint32_t)base);
+            if (base >= n_rays) break;
+            wave_next = base;
+            wave_end = base + rv.grab < n_rays ? base + rv.grab : n_rays;
+        }
+        const unsigned long long my = wave_next + lane;
+        wave_next += 64ull;
+        // ---- render_pixel's prologue for the tile's 64 rays (scene.rs:196-207)
+        uint32_t pl = 0, smp = 0;
+        bool alive = ray_index_to_pixel_tiled(rv, my, pl, smp);         // false: the padding of a partial tile
+        RayState r;
+        if (alive) gen_primary(sv, rv, pl, rv.sample_begin + smp, r);
+        else { r.pos = mk(0., 0., 0.); r.dir = mk(1., 0., 0.); r.result = mk(0., 0., 0.); r.light = mk(1., 1., 1.); r.key = 0; r.draw = 6; r.bounce = 0; }
+        const uint32_t ridx = (uint32_t)my;                             // (the host keeps rv.n_rays below 2^32)
+        const RayX rx = make_rayx(r.pos, r.dir);
+
+        // ---- closest_object (scene.rs:243-251), phase 1: one walk for the tile, f32 only
+        float best_up = -__builtin_inff();                              // -inf: this lane enters nothing
+        uint32_t qcnt = 0, nbox = 0, nleaf = 0;
+        bool overflow = false, walked = false;
+        Ray32S q;
+        SphereRay sr;
+        q.ix = q.iy = q.iz = 1.0f; q.nx = q.ny = q.nz = 0.0f; q.e = 0.0f;
+        sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
+        if (alive) {
+            const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
+                                     __builtin_fabsf((float)r.pos.z));
+            const bool in32 = omax <= sv.bvh_origin_limit;                                  // NaN origin -> exhaustive branch
+            if (in32 || omax <= sv.bvh_origin_limit * kBvhRange64) {
+                sphere_ray_from(sv, r.pos, r.dir, sr);
+                Ray32 q0;
+                make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q0);
+                q.ix = q0.ix; q.iy = q0.iy; q.iz = q0.iz; q.nx = q0.nx; q.ny = q0.ny; q.nz = q0.nz;
+                q.e = ray32_slack(q0.nx, q0.ny, q0.nz, in32);           // 0 inside origin_limit: the bits of Ray32
+                best_up = __builtin_inff();
+                walked = true;
+            }
+        }
+        const unsigned long long wm = __ballot(walked);
+        if (wm != 0ull) {
+            const uint32_t my_sgn = (q.ix < 0.0f ? 1u : 0u) | (q.iy < 0.0f ? 2u : 0u) | (q.iz < 0.0f ? 4u : 0u);
+            const uint32_t sgn = __builtin_amdgcn_readlane(my_sgn, (int)(__ffsll((long long)wm) - 1));
+            const uint32_t oct = __ballot(walked && my_sgn != sgn) == 0ull ? sgn : 8u;      // 8: the tile straddles an axis
+#define RTX_SPK_WALK(S) sph_packet_walk<S>(cnodes, csph, cprims, sv.bvh_root, q, sr, lq, tid, lane, best_up, qcnt, overflow, nbox, nleaf)
+            switch (oct) {
+                case 0: RTX_SPK_WALK(0); break;
+                case 1: RTX_SPK_WALK(1); break;
+                case 2: RTX_SPK_WALK(2); break;
+                case 3: RTX_SPK_WALK(3); break;
+                case 4: RTX_SPK_WALK(4); break;
+                case 5: RTX_SPK_WALK(5); break;
+                case 6: RTX_SPK_WALK(6); break;
+                case 7: RTX_SPK_WALK(7); break;
+                default: RTX_SPK_WALK(8); break;
+            }
+#undef RTX_SPK_WALK
+        }
+        // ---- phase 2, f64, all lanes together: the exact tests of the candidates that can still be the winner, the shapes
+        //      outside the tree, ray_hit
+        uint32_t first_id = 0;
+        if (alive) {
+            Hit h;
+            hit_init(h);
+            ++segs;
+            box_tests += nbox;
+            leaf_filters += nleaf;
+            if (walked && !overflow) {
+#pragma unroll 1
+                for (uint32_t e = 0; e < qcnt; ++e) {
+                    if (__uint_as_float(lq[(size_t)(kSphQueue + e) * kBvhThreads + tid]) <= best_up) {
+                        const uint32_t idx = lq[(size_t)e * kBvhThreads + tid];
+                        double t;
+                        if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
+                        exact += 1;
+                    }
+                }
+            } else {                                  // no walk (origin out of range / NaN) or a dropped candidate: every sphere
+                for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+                    double t;
+                    if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
+                }
+                exact += sv.n_spheres;
+            }
+            for (uint32_t k = 0; k < sv.n_planes; ++k) {
+                double t;
+                if (plane_distance(sv.planes[k], rx, &t)) hit_consider(h, t, sv.planes[k].id, 1, k);
+            }
+            for (uint32_t k = 0; k < sv.n_tri_filter; ++k) {       // the few triangles of a sphere scene (none of them in the tree)
+                const uint32_t tk = la.tri_fidx[k];
+                double t;
+                if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+            }
+            exact += sv.n_planes + sv.n_tri_filter;
+
+            // ---- render_ray's match arm + ray_hit (scene.rs:232-239, 260-278)
+            bool done = true;
+            if (h.id != kNone) {
+                advance_and_shade(sv, h, r);
+                first_id = h.id;
+                done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
+            }
+            if (done) {
+                store_sample(samples, rv, ridx, r.result);
+                alive = false;
+            }
+        }
+        sph_queue_append(sq, ctr, alive, r, ridx, first_id, lane, out_next, out_end);
+    }
+    sph_queue_close(sq, lane, out_next, out_end);
+    unsigned long long filt = box_tests + leaf_filters;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        segs += __shfl_xor(segs, off, 64);
+        exact += __shfl_xor(exact, off, 64);
+        filt += __shfl_xor(filt, off, 64);
+        box_tests += __shfl_xor(box_tests, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
+        if (segs) atomicAdd(&ctr[shard].segments, segs);
+        if (exact) atomicAdd(&ctr[shard].exact_tests, exact);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);
+    }
+}
+
 uint32_t bvh_spheres_spill_entries(const SceneView &sv)
 {
     const uint32_t need = 3u * sv.bvh_depth + 2u;       // a 4-wide node pushes at most 3 entries per level
@@ -264,22 +608,29 @@ size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus)
     return (size_t)bvh_spheres_spill_entries(sv) * (size_t)n_cus * kSphWavesPerSimd * kBvhThreads * sizeof(uint32_t);
 }
 
-// the survivors' queue of the two-stage form: 12 f64 + the ray index per slot, capacity = the launch's rays + what the waves'
-// reservations can leave unused, two u64 counters
+// the survivors' queue of the two-stage form: one 64-byte record per slot; capacity = the launch's rays (every ray can
+// survive: a closed scene) + the tail of one chunk per resident wave of stage 1, two u64 counters in front
 static uint64_t sph_queue_capacity(uint64_t n_rays, int n_cus)
 {
-    return n_rays + (uint64_t)n_cus * kSphWavesPerSimd * (kBvhThreads / 64) * (kSphQueueChunk + 64u) + kSphQueueChunk;
+    const int wpc = kSphWavesPerSimd > kSpkWaves ? kSphWavesPerSimd : kSpkWaves;
+    return n_rays + (uint64_t)n_cus * wpc * (kBvhThreads / 64) * kSphQueueChunk + kSphQueueChunk;
 }
 
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus)
 {
     const uint64_t cap = sph_queue_capacity(n_rays, n_cus);
-    return (size_t)(cap * (12 * sizeof(double) + sizeof(uint32_t)) + 16 * 256);
+    return (size_t)(cap * sizeof(SphSurvivor) + 2 * 256);
+}
+
+// may stage 1 walk as packets?  The ray queue in 8x8 tiles and a tree the wave-uniform stack holds.
+static bool sph_packets_ok(const SceneView &sv, const RowsView &rv)
+{
+    return rv.tiles_x != 0u && (rv.n_rays & 63ull) == 0ull && 3u * sv.bvh_depth + 2u <= (uint32_t)kSpkStack;
 }
 
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    void *queue_mem, hipStream_t stream)
+                                    void *queue_mem, uint32_t flags, hipStream_t stream)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -298,23 +649,25 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                            spill, spill_entries, sq);
         return hipGetLastError();
     }
-    // ---- two stages: carve the queue (every array on a 256-byte boundary), zero its two counters
+    // ---- two stages: carve the queue (256-byte boundaries), zero its two counters
     const uint64_t capacity = sph_queue_capacity(rv.n_rays, n_cus);
     char *p = static_cast<char *>(queue_mem);
-    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-    unsigned long long *ctrs = reinterpret_cast<unsigned long long *>(take(2 * sizeof(unsigned long long)));
-    for (int k = 0; k < 3; ++k) sq.pos[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
-    for (int k = 0; k < 3; ++k) sq.dir[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
-    for (int k = 0; k < 3; ++k) sq.res[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
-    for (int k = 0; k < 3; ++k) sq.lig[k] = reinterpret_cast<double *>(take(capacity * sizeof(double)));
-    sq.ridx = reinterpret_cast<uint32_t *>(take(capacity * sizeof(uint32_t)));
+    unsigned long long *ctrs = reinterpret_cast<unsigned long long *>(p);
+    sq.rec = reinterpret_cast<SphSurvivor *>(p + 256);
     sq.count = ctrs;
     sq.capacity = capacity;
     hipError_t e = hipMemsetAsync(ctrs, 0, 2 * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    auto k1 = deep ? trace_bvh_spheres_kernel<true, 1> : trace_bvh_spheres_kernel<false, 1>;
-    hipLaunchKernelGGL(k1, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter, nodes, la, spill,
-                       spill_entries, sq);
+    if ((flags & kSphNoPackets) == 0u && sph_packets_ok(sv, rv)) {
+        const uint64_t pcap = (uint64_t)n_cus * kSpkWaves;
+        const uint32_t pblocks = (uint32_t)(want < pcap ? want : pcap);
+        hipLaunchKernelGGL(trace_sph_packet_kernel, dim3(pblocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
+                           nodes, la, sq);
+    } else {
+        auto k1 = deep ? trace_bvh_spheres_kernel<true, 1> : trace_bvh_spheres_kernel<false, 1>;
+        hipLaunchKernelGGL(k1, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter, nodes, la, spill,
+                           spill_entries, sq);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     auto k2 = deep ? trace_bvh_spheres_kernel<true, 2> : trace_bvh_spheres_kernel<false, 2>;
     hipLaunchKernelGGL(k2, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, nodes, la, spill,

@@ -49,7 +49,7 @@ struct SceneView {
     uint32_t        n_bvh_nodes;
     uint32_t        bvh_root;                  // where a traversal starts: 0, or kBvhFlatNode when node 0 is a footprint node
     uint32_t        bvh_depth;
-    uint32_t        pad2_;
+    uint32_t        tuning;                    // RtxConfig.tuning (RTX_TUNE_* bits, include/rtx_hip.h): read by the host launchers only
     float           bvh_origin_limit;          // the f32 slab test is valid for ray origins with |o|_inf <= this
     uint32_t        bvh_flags;                 // bit 3: bvh_qnodes is valid;  bit 2: the tree holds nothing but (x, y)-footprint triangles (every node is a footprint node);
                                                // bit 0: the spheres are in the tree, bit 1: the first n_tri_tree filter records are
@@ -60,7 +60,8 @@ struct SceneView {
 // Which pixels/samples one launch covers.
 struct RowsView {
     uint32_t width, height;
-    uint32_t row_begin, row_stride, n_rows;
+    uint32_t row_begin, row_stride, n_rows;       // local row k is image row image_row(rv, k)
+    uint32_t row_block;            // rows per block of the band (1: single interleaved rows; 8: whole 8x8 ray tiles)
     uint32_t npix;                 // n_rows * width  (local pixels)
     uint32_t sample_begin;         // first sample index of this batch
     uint32_t n_samples;            // samples in this batch
@@ -73,6 +74,16 @@ struct RowsView {
     // sin/cos(vfov*(y/h-0.5)) per LOCAL row
     const double *sin_x, *cos_x, *sin_y, *cos_y;
 };
+
+// Local row k of a band -> image row.  The band is made of blocks of row_block consecutive image rows, row_stride rows
+// apart (block b of the band starts at row_begin + b * row_stride); row_block == 1 is the single-row form
+// row_begin + k * row_stride.  With row_block == 8 an 8x8 tile of the BVH kernels' ray queue (8 LOCAL rows) is 8x8
+// neighbouring pixels whatever the number of bands -- with single interleaved rows it is 8 columns x 8n image rows.
+RTX_HD uint32_t image_row(const RowsView &rv, uint32_t k)
+{
+    const uint32_t b = k / rv.row_block;
+    return rv.row_begin + b * rv.row_stride + (k - b * rv.row_block);
+}
 
 // Sharded counters (one slot per wave-id hash) summed on the host.
 struct Counters {
@@ -148,7 +159,7 @@ __device__ __forceinline__ void gen_primary(const SceneView &sv, const RowsView 
 {
     uint32_t k = pl / rv.width;                    // local row
     uint32_t x = pl - k * rv.width;
-    uint32_t y = rv.row_begin + k * rv.row_stride;
+    uint32_t y = image_row(rv, k);
     uint64_t pix = (uint64_t)y * rv.width + x;     // index in the FULL image keys the RNG
     // scene.rs:216-221 with the host-computed trig values
     V3 cam_space_dir = mk(rv.sin_x[x], rv.sin_y[k], rv.cos_x[x] * rv.cos_y[k]);

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
                 r.light = mk(st[9 * n_slots], st[10 * n_slots], st[11 * n_slots]);
                 const uint32_t k = pl / rv.width;
                 const uint32_t x = pl - k * rv.width;
-                const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                 r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                 r.draw = 6u + 2u * bnc;
                 r.bounce = bnc;
@@ -518,18 +518,31 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     o[2] = rust_as_u8(c[2] * 256.0);
 }
 
-// ------------------------------------------------------------------------------------------
-// multi-device gather epilogue: parts[k] holds the rows y = k, k + n, ... of the frame (band k, cap rows each)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void deinterleave_kernel(const double *__restrict__ parts, double *__restrict__ full,
-                                                           uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows)
+// render_to_image's `* 256` + saturating `as u8` (scene.rs:175-178) on the rows of a band, WITHOUT the flip (the gather
+// epilogue puts rows where they belong): what a device sends over xGMI is then 3 bytes per pixel instead of 24.
+__global__ __launch_bounds__(256) void quantize_values_kernel(const double *__restrict__ rgb, uint8_t *__restrict__ rgb8, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one double of the frame
-    const uint64_t row_doubles = (uint64_t)width * 3;
-    if (i >= row_doubles * height) return;
-    const uint32_t y = (uint32_t)(i / row_doubles);
-    const uint64_t c = i - (uint64_t)y * row_doubles;
-    full[i] = parts[((uint64_t)(y % n) * cap_rows + y / n) * row_doubles + c];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rgb8[i] = rust_as_u8(rgb[i] * 256.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-device gather epilogue: parts[p] (cap_rows rows each) holds band p of n: the blocks of `block` image rows
+// b = p, p + n, ... in order.  flip: output row height - 1 - y (render_to_image, scene.rs:176).
+// ------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__ parts, T *__restrict__ full,
+                                                           uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows,
+                                                           uint32_t block, uint32_t flip)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one value of the frame
+    const uint64_t row_vals = (uint64_t)width * 3;
+    if (i >= row_vals * height) return;
+    const uint32_t yo = (uint32_t)(i / row_vals);
+    const uint64_t c = i - (uint64_t)yo * row_vals;
+    const uint32_t y = flip ? height - 1u - yo : yo;
+    const uint32_t b = y / block, p = b % n, k = (b / n) * block + (y - b * block);
+    full[i] = parts[((uint64_t)p * cap_rows + k) * row_vals + c];
 }
 
 __global__ void debug_math_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
@@ -602,12 +615,16 @@ const MixVariant &mix_variant()
         make_variant<2, 128, 1024, 8, 4, 8>(),      // 8: 128-thread workgroups
 #endif
     };
-    static const int idx = [] {
+#ifdef RTX_MIXED_TUNING
+    static const int idx = [] {                           // tuning builds only: the production binary holds one shape
         const char *e = getenv("RTX_HIP_MIXED_VARIANT");
         int i = e ? atoi(e) : 0;
         return (i < 0 || i >= (int)(sizeof(table) / sizeof(table[0]))) ? 0 : i;
     }();
     return table[idx];
+#else
+    return table[0];
+#endif
 }
 
 }  // namespace
@@ -634,7 +651,11 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
     if (blocks == 0) return hipSuccess;
     const unsigned long long limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0ull : sv.max_bounces + 1ull;
     unsigned long long max_rounds = (rv.n_rays / slots_per_block + 2ull) * limit + 4ull;
+#ifdef RTX_MIXED_TUNING
     uint32_t verify_u = verify ? (getenv("RTX_HIP_DEBUG_PRINT") ? 2u : 1u) : 0u;
+#else
+    uint32_t verify_u = verify ? 1u : 0u;
+#endif
     void *args[] = { (void *)&d_sv, (void *)&d_rv, (void *)&samples, (void *)&state, (void *)&counters, (void *)&work_counter,
                      (void *)&verify_u, (void *)&max_rounds };
     return hipLaunchKernel(v.fn, dim3(blocks), dim3(v.threads), args, v.lds, stream);
@@ -658,13 +679,30 @@ hipError_t launch_quantize(const double *rgb, uint8_t *rgb8, uint32_t width, uin
     return hipGetLastError();
 }
 
+hipError_t launch_quantize_values(const double *rgb, uint8_t *rgb8, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_values_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, rgb, rgb8, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_deinterleave(const double *parts, double *full, uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows,
-                               hipStream_t stream)
+                               uint32_t block, hipStream_t stream)
 {
     const uint64_t total = (uint64_t)width * height * 3;
     if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(deinterleave_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, parts, full, width,
-                       height, n, cap_rows);
+    hipLaunchKernelGGL(deinterleave_kernel<double>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, parts, full, width,
+                       height, n, cap_rows, block, 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave_u8(const uint8_t *parts, uint8_t *full, uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows,
+                                  uint32_t block, bool flip, hipStream_t stream)
+{
+    const uint64_t total = (uint64_t)width * height * 3;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(deinterleave_kernel<uint8_t>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, parts, full, width,
+                       height, n, cap_rows, block, flip ? 1u : 0u);
     return hipGetLastError();
 }
 

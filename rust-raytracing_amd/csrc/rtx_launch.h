@@ -1,6 +1,7 @@
 // rtx_launch.h -- host-callable launchers of the gfx950 kernels (rtx_kernels.hip).
 #pragma once
 
+#include "../../include/rtx_hip.h"      // RTX_TUNE_* (SceneView::tuning)
 #include "rtx_device.h"
 
 namespace rtx {
@@ -32,12 +33,14 @@ hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const Ro
 // distance bounds, the exact tests after the walk, 5 waves per SIMD.  spill: bvh_spheres_spill_bytes() bytes (may be 0).
 uint32_t bvh_spheres_spill_entries(const SceneView &sv);
 size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
-// queue_mem: bvh_spheres_queue_bytes(rv.n_rays, n_cus) bytes for the two-stage form (primary rays in one launch, the rays that
-// survive their first hit in a second one fed from a queue), or null: one launch.
+// queue_mem: bvh_spheres_queue_bytes(rv.n_rays, n_cus) bytes for the two-stage form (primary rays in one launch -- one
+// wave-uniform packet walk per 8x8 tile when the ray queue is tiled; flags bit 0: per lane, for A/B runs -- the rays that
+// survive their first hit in a second one fed from a queue of 64-byte records), or null: one launch.  A survivor the queue
+// cannot take raises counters[1].pad_ (the launch's watchdog word, reported by the API).
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    void *queue_mem, hipStream_t stream);
+                                    void *queue_mem, uint32_t flags, hipStream_t stream);
 
 // RTX_KERNEL_BVH_REGROUP for trees that hold spheres only (rtx_bvh_spheres_pool.hip): every lane owns a pool of rays, the
 // f64 phase serves all of them, the walk runs the lane's pending segments one after the other with the waiting lanes
@@ -103,9 +106,14 @@ hipError_t launch_resolve(const double *samples, double *acc, double *out, const
 // render_to_image epilogue (scene.rs:175-178)
 hipError_t launch_quantize(const double *rgb, uint8_t *rgb8, uint32_t width, uint32_t height, hipStream_t stream);
 
-// rtx_render_devices' gather epilogue: parts = n bands of cap_rows rows each (band k = rows k, k + n, ...) -> full frame
+// rtx_render_devices' gather epilogue: parts = n bands of cap_rows rows each (band p = the blocks of `block` image rows
+// b = p, p + n, ... in order) -> the full frame; the u8 form optionally flips (render_to_image, scene.rs:176)
 hipError_t launch_deinterleave(const double *parts, double *full, uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows,
-                               hipStream_t stream);
+                               uint32_t block, hipStream_t stream);
+hipError_t launch_deinterleave_u8(const uint8_t *parts, uint8_t *full, uint32_t width, uint32_t height, uint32_t n, uint32_t cap_rows,
+                                  uint32_t block, bool flip, hipStream_t stream);
+// `* 256`, saturating `as u8` (scene.rs:175-178) of n values in place order (a band before it travels: no flip)
+hipError_t launch_quantize_values(const double *rgb, uint8_t *rgb8, uint64_t n, hipStream_t stream);
 
 // device evaluation of single f64 ops (tests: are / and sqrt correctly rounded, how far are sin/cos)
 // op: 0 a/b, 1 sqrt(a), 2 sin(a), 3 cos(a)

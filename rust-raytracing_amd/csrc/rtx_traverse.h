@@ -130,6 +130,22 @@ __device__ __forceinline__ float round_up32(double best)
     return b;
 }
 
+// wave-uniform reads through the scalar cache: the constant address space makes the compiler select s_load for them
+// (the packet walks of rtx_wavefront.hip and rtx_bvh_spheres.hip: one request per wave instead of 64 address-divergent ones)
+typedef float PkF4 __attribute__((ext_vector_type(4)));
+struct PkConst4 {
+    const __attribute__((address_space(4))) PkF4 *p;
+    __device__ __forceinline__ PkConst4 operator+(size_t i) const { return PkConst4{p + i}; }
+    __device__ __forceinline__ float4 operator[](size_t i) const { const PkF4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+};
+__device__ __forceinline__ PkConst4 pk_const(const float4 *p) { return PkConst4{(const __attribute__((address_space(4))) PkF4 *)(uintptr_t)p}; }
+__device__ __forceinline__ uint32_t pk_bits(float f) { return __builtin_amdgcn_readfirstlane(__float_as_uint(f)); }
+struct PkConstU32 {
+    const __attribute__((address_space(4))) uint32_t *p;
+    __device__ __forceinline__ uint32_t operator[](size_t i) const { return p[i]; }
+};
+__device__ __forceinline__ PkConstU32 pk_const(const uint32_t *p) { return PkConstU32{(const __attribute__((address_space(4))) uint32_t *)(uintptr_t)p}; }
+
 constexpr int kBvhQueue = 8;                // candidate shapes a lane may hold between two exact passes
 constexpr uint32_t kQueueTri = 0x80000000u; // queue entry: a triangle filter record (else a local sphere index)
 

@@ -225,15 +225,7 @@ constexpr int kPkWaves = RTX_PK_WAVES;                             // workgroups
 #endif
 constexpr int kPkWavesJoint = RTX_PK_WAVES_JOINT;
 
-// wave-uniform reads through the scalar cache: the constant address space makes the compiler select s_load for them
-typedef float PkF4 __attribute__((ext_vector_type(4)));
-struct PkConst4 {
-    const __attribute__((address_space(4))) PkF4 *p;
-    __device__ __forceinline__ PkConst4 operator+(size_t i) const { return PkConst4{p + i}; }
-    __device__ __forceinline__ float4 operator[](size_t i) const { const PkF4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
-};
-__device__ __forceinline__ PkConst4 pk_const(const float4 *p) { return PkConst4{(const __attribute__((address_space(4))) PkF4 *)(uintptr_t)p}; }
-__device__ __forceinline__ uint32_t pk_bits(float f) { return __builtin_amdgcn_readfirstlane(__float_as_uint(f)); }
+// (PkConst4 / pk_const / pk_bits: wave-uniform reads through the scalar cache, rtx_traverse.h)
 
 // PLAIN 1: every node is a footprint node, every leaf a triangle leaf (C3, C5).  PLAIN 0: a joint tree -- 3-D nodes over
 // sphere boxes and the footprints of the other planes, the (x, y) footprint sub-tree behind links with kBvhFlatNode, sphere
@@ -544,7 +536,7 @@ __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(co
                 if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                 else ray_index_to_pixel(rv, ridx, pl, smp);
                 const uint32_t k = pl / rv.width, x = pl - k * rv.width;
-                const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                 r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                 r.draw = 6u + 2u * level;
                 r.bounce = level;
@@ -652,7 +644,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const bool deep = spill_entries != 0u;
     const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
     const float4 *qnodes = reinterpret_cast<const float4 *>(sv.bvh_qnodes);
-    const bool qn = (sv.bvh_flags & 8u) != 0u && !std::getenv("RTX_HIP_NO_QNODES");
+    const bool qn = (sv.bvh_flags & 8u) != 0u && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
     const uint32_t trace_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfTraceWaves);
     const uint32_t shade_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfShadeWaves);   // (grid-stride)
     auto generate = [&](const WfState &s0) {
@@ -665,11 +657,11 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     // offer (levels 1-10 of the C5 band: 55 ms here, ~33 ms there), and 4 kernels per launch instead of 23 suit small frames
     // (C3 at 960x540x8: 15.2 ms against 21.1 all-wavefront and 25.4 megakernel; 480x270x8: 6.5 / 11.6 / 8.0).  With 4 triangles
     // per leaf and the queue-fed stage's own regrouping threshold it is level with the all-wavefront form even on C3 at
-    // 1080p x 64 spp (322.6 against 322.9 ms), so that form runs only on request: RTX_HIP_WF_PURE=1 (tests, A/B runs).
+    // 1080p x 64 spp (322.6 against 322.9 ms), so that form runs only on request: RTX_TUNE_WF_PURE (tests, A/B runs).
     const bool joint = (sv.bvh_flags & 4u) == 0u;      // spheres and / or footprints of other planes in the tree: packets + megakernel only
-    const bool hybrid = joint || !std::getenv("RTX_HIP_WF_PURE");
+    const bool hybrid = joint || (sv.tuning & RTX_TUNE_WF_PURE) == 0u;
     // level 0 as packets: the ray queue in 8x8 tiles, a tree the wave-uniform stack can hold
-    const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && (joint || !std::getenv("RTX_HIP_NO_PACKETS"));
+    const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && (joint || (sv.tuning & RTX_TUNE_NO_PACKETS) == 0u);
     if (joint && !packets) return hipErrorInvalidValue;      // (wavefront_mesh_supported() keeps the caller from asking)
     const float cmax_ru = std::nextafterf((float)sv.sphere_cmax, INFINITY);
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * (joint ? kPkWavesJoint : kPkWaves));

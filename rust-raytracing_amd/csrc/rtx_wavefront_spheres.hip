@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBvhThreads, 4) void wf_shade_spheres_kernel(const 
                 if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                 else ray_index_to_pixel(rv, ridx, pl, smp);
                 const uint32_t k = pl / rv.width, x = pl - k * rv.width;
-                const uint64_t pix = (uint64_t)(rv.row_begin + k * rv.row_stride) * rv.width + x;
+                const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                 r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                 r.draw = 6u + 2u * level;
                 r.bounce = level;

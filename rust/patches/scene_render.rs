@@ -9,12 +9,12 @@ impl Scene {
         let packed = self.pack(); // scene order is kept: it decides ties (scene.rs:250)
         let sc = self.to_c(&packed);
         let mut flat = vec![0f64; width * height * 3];
+        let devices = hip::render_devices();
         let rc = unsafe {
-            if self.config.devices.is_empty() {
+            if devices.is_empty() {
                 hip::rtx_render(&sc, width as u32, height as u32, flat.as_mut_ptr())
             } else {
-                hip::rtx_render_devices(&sc, width as u32, height as u32, self.config.devices.as_ptr(),
-                                        self.config.devices.len() as u32, flat.as_mut_ptr())
+                hip::rtx_render_devices(&sc, width as u32, height as u32, devices.as_ptr(), devices.len() as u32, flat.as_mut_ptr())
             }
         };
         hip::check(rc); // the reference panics on failure (scene.rs:168)
@@ -28,12 +28,12 @@ impl Scene {
         let packed = self.pack();
         let sc = self.to_c(&packed);
         let mut buf = vec![0u8; width * height * 3];
+        let devices = hip::render_devices();
         let rc = unsafe {
-            if self.config.devices.is_empty() {
+            if devices.is_empty() {
                 hip::rtx_render_to_image(&sc, width as u32, height as u32, buf.as_mut_ptr())
             } else {
-                hip::rtx_render_to_image_devices(&sc, width as u32, height as u32, self.config.devices.as_ptr(),
-                                                 self.config.devices.len() as u32, buf.as_mut_ptr())
+                hip::rtx_render_to_image_devices(&sc, width as u32, height as u32, devices.as_ptr(), devices.len() as u32, buf.as_mut_ptr())
             }
         };
         hip::check(rc);
@@ -69,7 +69,7 @@ impl Scene {
             config: hip::RtxConfig {
                 rays_per_pixel: c.rays_per_pixel as u64, max_bounces: c.max_bounces as u64,
                 focal_length: c.focal_length, focal_offset: c.focal_offset, non_focal_offset: c.non_focal_offset,
-                seed: c.seed, kernel: hip::RTX_KERNEL_AUTO, reserved: 0,
+                seed: hip::render_seed(), kernel: hip::RTX_KERNEL_AUTO, tuning: 0,
             },
             camera: hip::RtxCamera {
                 fov: cam.fov, position: cam.position.into(), direction: cam.get_direction().into(),

@@ -32,7 +32,8 @@ pub struct RtxConfig {
     pub non_focal_offset: f64,
     pub seed: u64,
     pub kernel: u32,
-    pub reserved: u32,
+    /// `RTX_TUNE_*` bits: A/B switches for tests and lab runs; 0 = what ships.
+    pub tuning: u32,
 }
 
 /// `Camera` (camera.rs:7-15); the matrices as three rows, row-major.  200 bytes.
@@ -89,9 +90,12 @@ extern "C" {
     pub fn rtx_scene_upload(scene: *const RtxScene, device: i32, out: *mut RtxSceneHandle) -> i32;
     pub fn rtx_scene_free(scene: RtxSceneHandle) -> i32;
     pub fn rtx_scene_set_config(scene: RtxSceneHandle, config: *const RtxConfig) -> i32;
+    pub fn rtx_scene_set_scratch_limit(scene: RtxSceneHandle, bytes: u64) -> i32;
     pub fn rtx_scene_append_objects(scene: RtxSceneHandle, objects: *const RtxObject, n_objects: u64) -> i32;
     pub fn rtx_scene_set_camera(scene: RtxSceneHandle, camera: *const RtxCamera) -> i32;
     pub fn rtx_render_rows(scene: RtxSceneHandle, width: u32, height: u32, row_begin: u32, row_stride: u32, n_rows: u32, d_out_rgb: *mut f64, stream: *mut c_void, stats: *mut RtxStats) -> i32;
+    pub fn rtx_blocks_row_count(height: u32, block_rows: u32, part: u32, n_parts: u32) -> u32;
+    pub fn rtx_render_blocks(scene: RtxSceneHandle, width: u32, height: u32, block_rows: u32, part: u32, n_parts: u32, d_out_rgb: *mut f64, stream: *mut c_void, stats: *mut RtxStats) -> i32;
     pub fn rtx_quantize_image_device(d_rgb: *const f64, width: u32, height: u32, d_rgb8: *mut u8, device: i32, stream: *mut c_void) -> i32;
 }
 
@@ -101,4 +105,35 @@ pub fn check(rc: i32) {
         let msg = unsafe { std::ffi::CStr::from_ptr(rtx_last_error()) }.to_string_lossy().into_owned();
         panic!("rtx_hip (status {rc}): {msg}");
     }
+}
+
+// ---- what the device path needs and the reference's types cannot carry -------------------------------------------------
+// `Config` and `Scene` are plain `pub` structs that users build with struct literals (scene.rs:16-28, :78-85), so the shim
+// adds NO field to them.  The two settings the device path adds are process-wide instead, set through these functions:
+//   * the render seed: the reference draws from fastrand's never-seeded thread-local generator on one thread per row
+//     (math/vector.rs:31-38, scene.rs:151) -- every run renders a different image.  Default here: a fresh key per
+//     `render()` call (same behaviour); `set_render_seed(Some(k))` makes renders reproducible (they never were).
+//   * the GPUs a frame is partitioned over (blocks of rows, one gather); default: device 0.
+use std::sync::atomic::{AtomicBool, AtomicU64, Ordering};
+use std::sync::Mutex;
+
+static SEED_FIXED: AtomicBool = AtomicBool::new(false);
+static SEED: AtomicU64 = AtomicU64::new(0);
+static DEVICES: Mutex<Vec<i32>> = Mutex::new(Vec::new());
+
+pub fn set_render_seed(seed: Option<u64>) {
+    if let Some(s) = seed { SEED.store(s, Ordering::Relaxed); }
+    SEED_FIXED.store(seed.is_some(), Ordering::Release);
+}
+
+pub fn render_seed() -> u64 {
+    if SEED_FIXED.load(Ordering::Acquire) { SEED.load(Ordering::Relaxed) } else { fastrand::u64(..) }
+}
+
+pub fn set_render_devices(devices: &[i32]) {
+    *DEVICES.lock().unwrap() = devices.to_vec();
+}
+
+pub fn render_devices() -> Vec<i32> {
+    DEVICES.lock().unwrap().clone()
 }

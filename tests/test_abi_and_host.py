@@ -139,6 +139,12 @@ def test_rust_shim_matches_the_header(tmp_path):
     # the shim's Scene::render body goes through these and nothing else
     body = open(os.path.join(ROOT, "rust", "patches", "scene_render.rs")).read()
     assert set(re.findall(r"hip::(rtx_\w+)", body)) <= set(r_fns)
+    # the shim adds no field to the reference's pub structs (users build Config / Scene with struct literals, scene.rs:16-28,
+    # :78-85) and no builder that consumes self (every reference builder takes &self, scene.rs:38-53)
+    assert not os.path.exists(os.path.join(ROOT, "rust", "patches", "config_seed.rs"))
+    assert "self.config.seed" not in body and "self.config.devices" not in body
+    for f in os.listdir(os.path.join(ROOT, "rust", "patches")):
+        assert not re.search(r"pub\s+fn\s+with_\w+\s*\(\s*self\b", open(os.path.join(ROOT, "rust", "patches", f)).read()), f
 
 
 def test_cpp_host_header_compiles(tmp_path):

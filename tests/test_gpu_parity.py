@@ -274,10 +274,16 @@ def test_spheres_kernel_paths(gpu, oracle):
     import torch
     from rust_raytracing_amd import scenes
 
-    def both(objs, cam, w=64, h=36, spp=2, **cfg):
+    def both(objs, cam, w=64, h=36, spp=2, scratch=0, **cfg):
+        # RTX_KERNEL_BVH three times: one stage (what a frame this small takes), and forced into the two-stage form of big
+        # frames -- stage 1 as one packet walk per 8x8 tile (trace_sph_packet_kernel) and per lane --, so that every edge
+        # case below also crosses the packets, the survivors' queue and the queue-fed stage 2
         out = []
-        for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_KERNEL_EXACT):
-            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
+        for kern, tune in ((gpu.RTX_KERNEL_BVH, 0), (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE),
+                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS),
+                           (gpu.RTX_KERNEL_BVH_REGROUP, 0), (gpu.RTX_KERNEL_WAVEFRONT, 0), (gpu.RTX_KERNEL_EXACT, 0)):
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, tuning=tune, **cfg).upload(0)
+            hnd.set_scratch_limit(scratch)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
             hnd.close()
@@ -322,20 +328,18 @@ def test_spheres_kernel_paths(gpu, oracle):
     # hit, from a queue whose unused reserved slots are marked dead): against one stage and the exhaustive kernel, with
     # partial tiles, and with a scratch cap that cuts the frame into several launches
     big = {}
-    for name, env in (("two", {}), ("one", {"RTX_HIP_BVH_ONE_STAGE": "1"}), ("two_batched", {"RTX_HIP_SCRATCH_MB": "200"})):
-        os.environ.update(env)
-        try:
-            hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_BVH, rays_per_pixel=2, seed=42).upload(0)
-            buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
-            st = hnd.render_rows(1203, 997, 0, 1, 997, buf.data_ptr())
-            hnd.close()
-        finally:
-            for k in env:
-                del os.environ[k]
-        big[name] = (buf.cpu().numpy(), st.segments, st.trace_launches)
+    for name, tune, limit in (("two", 0, 0), ("two_lanes", gpu.RTX_TUNE_NO_PACKETS, 0), ("one", gpu.RTX_TUNE_ONE_STAGE, 0),
+                              ("two_batched", 0, 150 << 20)):
+        hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_BVH, rays_per_pixel=2, seed=42, tuning=tune).upload(0)
+        hnd.set_scratch_limit(limit)
+        buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(1203, 997, 0, 1, 997, buf.data_ptr())
+        hnd.close()
+        big[name] = (buf.cpu().numpy(), st.segments, st.trace_launches, st.box_tests)
     assert big["two"][2] == 1 and big["one"][2] == 1 and big["two_batched"][2] == 2
-    assert np.array_equal(big["two"][0], big["one"][0]) and big["two"][1] == big["one"][1]
-    assert np.array_equal(big["two"][0], big["two_batched"][0]) and big["two"][1] == big["two_batched"][1]
+    for name in ("two_lanes", "one", "two_batched"):
+        assert np.array_equal(big["two"][0], big[name][0]) and big["two"][1] == big[name][1], name
+    assert big["two"][3] > big["two_lanes"][3]                                   # (a packet tests the union of its rays' nodes)
     hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=2, seed=42).upload(0)
     buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
     ste = hnd.render_rows(1203, 997, 0, 1, 997, buf.data_ptr())
@@ -345,11 +349,7 @@ def test_spheres_kernel_paths(gpu, oracle):
     bouncy["base_color"] = 0.97; bouncy["emission_color"] *= 0.05              # paths survive: more levels than one host-side chunk
     both(bouncy, scenes.CAMERA, max_bounces=40)
     both(bouncy, scenes.CAMERA, max_bounces=0)
-    os.environ["RTX_HIP_SCRATCH_MB"] = "1"                                     # one sample per batch
-    try:
-        both(co, scenes.CAMERA, spp=3)
-    finally:
-        del os.environ["RTX_HIP_SCRATCH_MB"]
+    both(co, scenes.CAMERA, spp=3, scratch=300000)                             # 2560 ray slots x 96 B: one sample per batch
 
 
 def test_mesh_kernel_paths(gpu, oracle):
@@ -366,20 +366,16 @@ def test_mesh_kernel_paths(gpu, oracle):
     import torch
     from rust_raytracing_amd import scenes
 
-    def both(objs, cam, w=64, h=36, spp=2, **cfg):
+    def both(objs, cam, w=64, h=36, spp=2, scratch=0, **cfg):
         out = []
-        for kern, env in ((gpu.RTX_KERNEL_BVH_REGROUP, None), (gpu.RTX_KERNEL_WAVEFRONT, "RTX_HIP_WF_PURE"),
-                          (gpu.RTX_KERNEL_WAVEFRONT, "RTX_HIP_WF_HYBRID"), (gpu.RTX_KERNEL_EXACT, None)):
-            if env:
-                os.environ[env] = "1"              # every level in the wavefront form / the megakernel from level 1 on
-            try:
-                hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, **cfg).upload(0)
-                buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
-                st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-                hnd.close()
-            finally:
-                if env:
-                    del os.environ[env]
+        # RTX_KERNEL_WAVEFRONT twice: every level in the wavefront form / the megakernel from level 1 on (the default)
+        for kern, tune in ((gpu.RTX_KERNEL_BVH_REGROUP, 0), (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_WF_PURE),
+                           (gpu.RTX_KERNEL_WAVEFRONT, 0), (gpu.RTX_KERNEL_EXACT, 0)):
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, tuning=tune, **cfg).upload(0)
+            hnd.set_scratch_limit(scratch)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            hnd.close()
             out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
         for o in out[:-1]:
             assert np.array_equal(o[0], out[-1][0]) and o[1] == out[-1][1]
@@ -405,11 +401,7 @@ def test_mesh_kernel_paths(gpu, oracle):
     bouncy["base_color"] = 0.97; bouncy["emission_color"] *= 0.05              # paths survive: up to 41 / 1 segments per ray
     both(bouncy, scenes.CAMERA, max_bounces=40)
     both(bouncy, scenes.CAMERA, max_bounces=0)
-    os.environ["RTX_HIP_SCRATCH_MB"] = "1"                                     # 64 x 36 x 300 B per sample: one sample per batch
-    try:
-        both(co, scenes.CAMERA, spp=3)
-    finally:
-        del os.environ["RTX_HIP_SCRATCH_MB"]
+    both(co, scenes.CAMERA, spp=3, scratch=1 << 20)                            # 64 x 36 x 300 B per sample: one sample per batch
     joint = np.concatenate([scenes.compact(scenes.random_spheres(300, 3), k=0.06, x0=5.0), co[:1500], scenes.axis_aligned_mesh(60, x0=4.0, span=2.0)])
     stj = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), joint))
     assert stj["flags"] == 3 and stj["tri_other_footprints"] > 100
@@ -424,8 +416,8 @@ def test_mesh_kernel_paths(gpu, oracle):
 def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
     """AUTO on a pure (x, y)-footprint mesh with >= 2^20 rays: RTX_KERNEL_WAVEFRONT, whose level 0 walks each 8x8 tile of
     primary rays as one packet (wf_trace_packet_kernel); the regrouping megakernel continues from the level-1 queue (the
-    default below 2^24 rays or for a tree beyond the L2s) or every level stays in the wavefront form (RTX_HIP_WF_PURE).  Same
-    bits as the megakernel alone, as the wavefront form with per-lane walks at level 0 (RTX_HIP_NO_PACKETS), and the
+    default below 2^24 rays or for a tree beyond the L2s) or every level stays in the wavefront form (RTX_TUNE_WF_PURE).  Same
+    bits as the megakernel alone, as the wavefront form with per-lane walks at level 0 (RTX_TUNE_NO_PACKETS), and the
     oracle on scattered pixels; below the ray count AUTO stays with the megakernel.  A frame that does not divide into
     tiles and a row band are included."""
     import torch
@@ -433,36 +425,27 @@ def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
     objs = scenes.light_every(scenes.compact(scenes.random_triangles(30000, 8), k=0.06, x0=5.0))
     w, h, spp = 517, 509, 16                                                  # 4.21e6 rays, partial tiles on both edges
 
-    def render(kernel, rb=0, rs=1, rows=h, **env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            hnd = hip_scene(gpu, objs, kernel=kernel, rays_per_pixel=spp, seed=42).upload(0)       # (objs, spp: the enclosing scope's current values)
-            buf = torch.zeros((rows, w, 3), dtype=torch.float64, device="cuda:0")
-            st = hnd.render_rows(w, h, rb, rs, rows, buf.data_ptr())
-            hnd.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = v
+    def render(kernel, rb=0, rs=1, rows=h, tuning=0):
+        hnd = hip_scene(gpu, objs, kernel=kernel, rays_per_pixel=spp, seed=42, tuning=tuning).upload(0)       # (objs, spp: the enclosing scope's current values)
+        buf = torch.zeros((rows, w, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(w, h, rb, rs, rows, buf.data_ptr())
+        hnd.close()
         return buf.cpu().numpy(), st
 
     auto, st = render(gpu.RTX_KERNEL_AUTO)
     assert st.kernel == gpu.RTX_KERNEL_WAVEFRONT
     mega, stm = render(gpu.RTX_KERNEL_BVH_REGROUP)
     assert np.array_equal(auto, mega) and st.segments == stm.segments
-    pure, stp = render(gpu.RTX_KERNEL_WAVEFRONT, RTX_HIP_WF_PURE="1")
+    pure, stp = render(gpu.RTX_KERNEL_WAVEFRONT, tuning=gpu.RTX_TUNE_WF_PURE)
     assert np.array_equal(auto, pure) and stp.segments == st.segments
-    for mode in ("RTX_HIP_WF_PURE", "RTX_HIP_WF_HYBRID"):
-        lanes, stl = render(gpu.RTX_KERNEL_WAVEFRONT, RTX_HIP_NO_PACKETS="1", **{mode: "1"})
+    for mode in (gpu.RTX_TUNE_WF_PURE, 0):                                     # every level in the wavefront form / the hybrid
+        lanes, stl = render(gpu.RTX_KERNEL_WAVEFRONT, tuning=gpu.RTX_TUNE_NO_PACKETS | mode)
         assert np.array_equal(auto, lanes) and stl.box_tests < st.box_tests    # (a packet tests the union of its rays' nodes)
     xs, ys = _scattered_pixels(auto, 150, 40, seed=3)
     ref = oracle.render_pixels(oracle.make_scene(objs, DEFAULT_CAM, rays_per_pixel=spp, seed=42), w, h, xs, ys)
     assert max_abs_diff(auto[ys, xs], ref) <= ATOL
-    for mode in ("RTX_HIP_WF_PURE", "RTX_HIP_WF_HYBRID"):
-        band, stb = render(gpu.RTX_KERNEL_WAVEFRONT, rb=3, rs=8, rows=len(range(3, h, 8)), **{mode: "1"})
+    for mode in (gpu.RTX_TUNE_WF_PURE, 0):
+        band, stb = render(gpu.RTX_KERNEL_WAVEFRONT, rb=3, rs=8, rows=len(range(3, h, 8)), tuning=mode)
         assert np.array_equal(band, auto[3::8])
     small, sts = render(gpu.RTX_KERNEL_AUTO, rows=h // 8)                       # 5.2e5 rays: the megakernel
     assert sts.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(small, auto[:h // 8])
@@ -480,11 +463,12 @@ def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
 
 
 def test_ab_knobs_keep_the_bits(gpu):
-    """Every A/B environment knob of the library selects another schedule, node format or tree build -- never other bits.
-    Each one, on a pure mesh, a sphere scene and a joint scene, for the tree kernels, against the exhaustive f64 kernel:
-    RTX_HIP_BVH_CLASSIC (round 1's kernels), RTX_HIP_NO_QNODES (96-byte instead of 64-byte nodes), RTX_HIP_NO_TILES (ray
-    queue in rows instead of 8x8 tiles: also the wavefront form without packets), RTX_HIP_TRI_LEAF (1 / 2 / 6 triangles per
-    leaf instead of 4; larger values are clamped to 6), RTX_HIP_BVH_THRESH (regrouping threshold), RTX_HIP_BVH_MEDIAN (median splits instead of SAH)."""
+    """Every A/B switch of RtxConfig.tuning selects another schedule, node format or tree build -- never other bits (and the
+    library reads no environment variable for any of them).  Each one, on a pure mesh, a sphere scene and a joint scene, for
+    the tree kernels, against the exhaustive f64 kernel: RTX_TUNE_BVH_CLASSIC (round 1's kernels), NO_QNODES (96-byte instead
+    of 64-byte nodes), NO_TILES (ray queue in rows instead of 8x8 tiles: also no packets), TRI_LEAF (1 / 2 / 6 triangles per
+    leaf instead of the default; larger values are clamped to 6), THRESH (regrouping threshold), BVH_MEDIAN (median splits
+    instead of SAH), TWO_STAGE / ONE_STAGE / NO_PACKETS (the sphere kernel's stages)."""
     import torch
     from rust_raytracing_amd import scenes
     mesh = scenes.light_every(scenes.compact(scenes.random_triangles(3000, 16), k=0.05, x0=5.0))
@@ -492,27 +476,24 @@ def test_ab_knobs_keep_the_bits(gpu):
     joint = np.concatenate([balls[:200], mesh[:800], scenes.axis_aligned_mesh(40, x0=4.0, span=2.0)])
     w, h, spp = 72, 40, 2
 
-    def render(objs, kern):
-        hnd = hip_scene(gpu, objs, cam=scenes.CAMERA, kernel=kern, rays_per_pixel=spp, seed=9).upload(0)
+    def render(objs, kern, tuning=0):
+        hnd = hip_scene(gpu, objs, cam=scenes.CAMERA, kernel=kern, rays_per_pixel=spp, seed=9, tuning=tuning).upload(0)
         buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
         hnd.close()
         return buf.cpu().numpy(), st.segments
 
     ref = {name: render(o, gpu.RTX_KERNEL_EXACT) for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint))}
-    knobs = [{}, {"RTX_HIP_BVH_CLASSIC": "1"}, {"RTX_HIP_NO_QNODES": "1"}, {"RTX_HIP_NO_TILES": "1"}, {"RTX_HIP_TRI_LEAF": "1"},
-             {"RTX_HIP_TRI_LEAF": "2"}, {"RTX_HIP_TRI_LEAF": "6"}, {"RTX_HIP_TRI_LEAF": "8"}, {"RTX_HIP_BVH_THRESH": "4"}, {"RTX_HIP_BVH_THRESH": "48"}, {"RTX_HIP_BVH_MEDIAN": "1"},
-             {"RTX_HIP_NO_QNODES": "1", "RTX_HIP_WF_PURE": "1"}, {"RTX_HIP_TRI_LEAF": "6", "RTX_HIP_WF_HYBRID": "1"}]
-    for env in knobs:
-        os.environ.update(env)
-        try:
-            for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint)):
-                for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT):
-                    img, segs = render(o, kern)
-                    assert np.array_equal(img, ref[name][0]) and segs == ref[name][1], (env, name, kern)
-        finally:
-            for k in env:
-                del os.environ[k]
+    leaf, thresh = gpu.RTX_TUNE_TRI_LEAF_SHIFT, gpu.RTX_TUNE_THRESH_SHIFT
+    knobs = [0, gpu.RTX_TUNE_BVH_CLASSIC, gpu.RTX_TUNE_NO_QNODES, gpu.RTX_TUNE_NO_TILES, 1 << leaf, 2 << leaf, 6 << leaf, 8 << leaf,
+             4 << thresh, 48 << thresh, gpu.RTX_TUNE_BVH_MEDIAN, gpu.RTX_TUNE_NO_QNODES | gpu.RTX_TUNE_WF_PURE, 6 << leaf,
+             gpu.RTX_TUNE_TWO_STAGE, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_TILES,
+             gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_TWO_STAGE]
+    for tune in knobs:
+        for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint)):
+            for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT):
+                img, segs = render(o, kern, tune)
+                assert np.array_equal(img, ref[name][0]) and segs == ref[name][1], (tune, name, kern)
 
 
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
@@ -582,23 +563,37 @@ def test_candidate_queue_overflow_falls_back_to_exact_sweep(gpu, oracle):
 
 
 def test_partition_by_rows_is_invisible(gpu):
-    """Bands rendered separately (as the ranks of a multi-GPU job do) reassemble to the one-shot image bit for bit."""
+    """Bands rendered separately (as the ranks of a multi-GPU job do) reassemble to the one-shot image bit for bit: single
+    interleaved rows (rtx_render_rows) and blocks of 8 / 5 rows (rtx_render_blocks; 8 = whole ray tiles, what the multi-GPU
+    paths use), a height that does not divide, more parts than blocks; the per-part segment counts add up to the frame's."""
     import torch
     from rust_raytracing_amd import scenes, tiles
     objs = scenes.compact(scenes.random_spheres(500, 2), k=0.3)
-    w, h, world = 80, 45, 4
+    w, h = 80, 45
     sc = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=3), gpu.Camera(*scenes.CAMERA), objs)
     full = sc.render(w, h)
     hnd = sc.upload(0)
-    parts = []
-    for r in range(world):
-        rb, rs, n = tiles.rows_for_rank(h, r, world)
-        band = tiles.alloc_band(h, w, world, "cuda:0")
-        hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
-        parts.append(band)
-    got = tiles.deinterleave(parts, h, w).cpu().numpy()
+    whole = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    total = hnd.render_rows(w, h, 0, 1, h, whole.data_ptr()).segments
+    assert np.array_equal(whole.cpu().numpy(), full)
+    for world, block in ((4, 1), (4, 8), (3, 8), (8, 8), (2, 5)):
+        parts, segs = [], 0
+        for r in range(world):
+            part = tiles.Partition(h, r, world, block)
+            band = part.alloc_band(w, "cuda:0")
+            if block == 1:
+                rb, rs, n = tiles.rows_for_rank(h, r, world)
+                assert n == part.n_rows
+                st = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+            else:
+                st = part.render(hnd, w, band, want_stats=True)
+            assert st.primary_rays == part.n_rows * w * 3
+            segs += st.segments
+            parts.append(band)
+        got = tiles.deinterleave(parts, h, w, block).cpu().numpy()
+        assert np.array_equal(got, full), (world, block)
+        assert segs == total
     hnd.close()
-    assert np.array_equal(got, full)
 
 
 def test_resident_scene_config_and_camera_updates(gpu, oracle):
@@ -657,14 +652,20 @@ def test_resident_scene_append_objects(gpu, oracle):
     hnd.close()
 
 
-def test_sample_batching_keeps_the_left_fold(gpu, oracle, monkeypatch):
+def test_sample_batching_keeps_the_left_fold(gpu, oracle):
     """With scratch capped, samples are traced in several batches; the fold order (iter_ops.rs:4-8) must not change."""
+    import torch
     from rust_raytracing_amd import scenes
     objs = scenes.three_spheres()
     cfg = dict(rays_per_pixel=7, seed=5)
     a = hip_render(gpu, objs, 300, 200, **cfg)
-    monkeypatch.setenv("RTX_HIP_SCRATCH_MB", "3")          # 300*200*24 B = 1.44 MB per sample -> batches of 2
-    b = hip_render(gpu, objs, 300, 200, **cfg)
+    hnd = hip_scene(gpu, objs, **cfg).upload(0)
+    hnd.set_scratch_limit(4 << 20)                          # 300*200*32 B = 1.92 MB per sample -> batches of 2
+    buf = torch.zeros((200, 300, 3), dtype=torch.float64, device="cuda:0")
+    st = hnd.render_rows(300, 200, 0, 1, 200, buf.data_ptr())
+    hnd.close()
+    b = buf.cpu().numpy()
+    assert st.trace_launches == 4
     assert np.array_equal(a, b)
     ref = oracle_render(oracle, objs, 300, 200, **cfg)
     assert max_abs_diff(a, ref) <= ATOL
@@ -861,26 +862,32 @@ def test_cpp_resident_scene_camera_updates(gpu, oracle, tmp_path):
 
 # ---- BASELINE.json's full-size workload through size-independent properties ----------------------------------
 def test_c4_shaped_band_of_one_rank(gpu, oracle):
-    """BASELINE.json configs[3] is 3840x2160 over 8 GPUs: render the band rank 3 of 8 would own (270 interleaved rows,
-    2 spp here, scratch capped so that the samples are traced in batches) and check three of its rows against the oracle."""
+    """BASELINE.json configs[3] is 3840x2160 over 8 GPUs: render the band rank 3 of 8 would own (270 interleaved rows) AS
+    BENCHED -- the sphere kernel's two stages (packets for the primary rays, the survivors' queue, the queue-fed stage) and
+    sample batching together: 4 spp with the scratch capped so that a batch holds 2 samples (2.09e6 ray slots >= 2^20) and
+    two batches run -- and check three of its rows against the oracle; the one-stage form must give the same bits."""
     import torch
     from rust_raytracing_amd import scenes, tiles
     objs = scenes.random_spheres(10000, 1)
     w, h, world, rank = 3840, 2160, 8, 3
-    os.environ["RTX_HIP_SCRATCH_MB"] = "40"          # 270*3840*24 B = 24.9 MB per sample -> 1 sample per batch
-    try:
-        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=2, seed=42), gpu.Camera(*scenes.CAMERA), objs).upload(0)
-        rb, rs, n = tiles.rows_for_rank(h, rank, world)
-        band = tiles.alloc_band(h, w, world, "cuda:0")
-        st = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+    part = tiles.Partition(h, rank, world)             # blocks of 8 rows 3, 11, 19, ...: 272 rows
+    n = part.n_rows
+    res = {}
+    for name, tune in (("two", 0), ("one", gpu.RTX_TUNE_ONE_STAGE)):
+        hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=4, seed=42, tuning=tune), gpu.Camera(*scenes.CAMERA), objs).upload(0)
+        hnd.set_scratch_limit(280 << 20)               # 480*34*64 slots * (32 + 64) B = 100.3 MB per sample -> 2 samples per batch
+        band = part.alloc_band(w, "cuda:0")
+        st = part.render(hnd, w, band, want_stats=True)
         hnd.close()
-    finally:
-        del os.environ["RTX_HIP_SCRATCH_MB"]
-    assert st.trace_launches == 2 and st.primary_rays == n * w * 2
-    got = band[:n].cpu().numpy()
-    osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=2, seed=42)
-    for k in (0, 133, 269):
-        y = rb + k * rs
+        res[name] = (band[:n].cpu().numpy(), st)
+    got, st = res["two"]
+    assert st.kernel == gpu.RTX_KERNEL_BVH and st.trace_launches == 2 and st.primary_rays == n * w * 4
+    assert np.array_equal(got, res["one"][0]) and st.segments == res["one"][1].segments
+    assert st.box_tests > res["one"][1].box_tests             # stage 1 ran as packets (a packet tests the union of its rays' nodes)
+    osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=4, seed=42)
+    assert n == 272 and part.rows[0] == 24 and part.rows[8] == 88
+    for k in (0, 133, 271):
+        y = int(part.rows[k])
         ref = oracle.render(osc, w, h, row_begin=y, row_stride=h)       # exactly one row
         assert max_abs_diff(got[k], ref[y]) <= ATOL
     assert got.mean() > 0.01
@@ -895,12 +902,12 @@ def test_c5_shaped_rows_of_one_rank(gpu):
     from rust_raytracing_amd import scenes, tiles
     objs = scenes.random_triangles(1000000, 3, box=2.0)
     w, h, world, rank = 3840, 2160, 8, 5
-    rb, rs, n = tiles.rows_for_rank(h, rank, world)
+    y0 = int(tiles.Partition(h, rank, world).rows[100])                        # row 100 of the band: 3 consecutive image rows of one block
     out = {}
     for kern in (gpu.RTX_KERNEL_AUTO, gpu.RTX_KERNEL_EXACT):
         hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=1, seed=42, kernel=kern), gpu.Camera(*scenes.CAMERA), objs).upload(0)
         buf = torch.zeros((3, w, 3), dtype=torch.float64, device="cuda:0")
-        st = hnd.render_rows(w, h, rb + 100 * rs, rs, 3, buf.data_ptr())       # rows 100..102 of the band
+        st = hnd.render_rows(w, h, y0, 1, 3, buf.data_ptr())
         out[kern] = (buf.cpu().numpy(), st.segments, st.kernel)
         hnd.close()
     a, e = out[gpu.RTX_KERNEL_AUTO], out[gpu.RTX_KERNEL_EXACT]
@@ -950,13 +957,9 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
         buf.zero_()
         st2 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
         assert st2.kernel == kern and np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
-    os.environ["RTX_HIP_WF_PURE"] = "1"                                          # every level in the wavefront form
-    try:
-        hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT))
-        buf.zero_()
-        st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-    finally:
-        del os.environ["RTX_HIP_WF_PURE"]
+    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT, tuning=gpu.RTX_TUNE_WF_PURE))   # every level in the wavefront form
+    buf.zero_()
+    st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
     assert st3.kernel == gpu.RTX_KERNEL_WAVEFRONT and np.array_equal(a, buf.cpu().numpy()) and st3.segments == st.segments
     hnd.close()
     xs, ys = _scattered_pixels(a, 200, 100, seed=11)
@@ -970,7 +973,7 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
 
 def test_c5_band_against_the_oracle(gpu, oracle):
     """BASELINE.json configs[4] on its own scene: 1M random triangles (scene seed 3, box x2), 3840x2160, the band rank 5
-    of 8 owns (270 interleaved rows), AUTO (at 1 spp just under 2^20 rays: the regrouping BVH kernel, deep tree -> the HBM
+    of 8 owns (272 rows in blocks of 8), AUTO (at 1 spp just under 2^20 rays: the regrouping BVH kernel, deep tree -> the HBM
     stack-spill variant) and the wavefront form AUTO takes from 2^20 rays on (packets at level 0 over a tree that exceeds
     the L2s, the regrouping kernel from the level-1 queue), bit for bit.  100+ scattered pixels of the band against the
     oracle, which tests all 10^6 triangles per segment."""
@@ -978,20 +981,21 @@ def test_c5_band_against_the_oracle(gpu, oracle):
     from rust_raytracing_amd import scenes, tiles
     objs = scenes.random_triangles(1000000, 3, box=2.0)
     w, h, world, rank, spp = 3840, 2160, 8, 5, 1
-    rb, rs, n = tiles.rows_for_rank(h, rank, world)
+    part = tiles.Partition(h, rank, world)                      # blocks of 8 rows 5, 13, 21, ...
+    n = part.n_rows
     hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, seed=42), gpu.Camera(*scenes.CAMERA), objs).upload(0)
-    band = tiles.alloc_band(h, w, world, "cuda:0")
-    st = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+    band = part.alloc_band(w, "cuda:0")
+    st = part.render(hnd, w, band, want_stats=True)
     assert st.kernel == gpu.RTX_KERNEL_BVH_REGROUP and st.primary_rays == n * w * spp
     assert n * w * spp <= st.segments <= 11 * n * w * spp
     got = band[:n].cpu().numpy()
     hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT))
     band.zero_()
-    stw = hnd.render_rows(w, h, rb, rs, n, band.data_ptr())
+    stw = part.render(hnd, w, band, want_stats=True)
     hnd.close()
     assert stw.kernel == gpu.RTX_KERNEL_WAVEFRONT and stw.segments == st.segments and np.array_equal(got, band[:n].cpu().numpy())
     xs, ks = _scattered_pixels(got, 64, 40, seed=12)            # ks = row index inside the band
-    ys = (rb + ks.astype(np.int64) * rs).astype(np.uint32)
+    ys = part.rows[ks.astype(np.int64)].astype(np.uint32)
     osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=spp, seed=42)
     ref = oracle.render_pixels(osc, w, h, xs, ys)
     assert max_abs_diff(got[ks, xs], ref) <= ATOL

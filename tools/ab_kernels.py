@@ -1,6 +1,10 @@
-"""Kernel A against kernel B on a BASELINE config (same box, same process): time, rates, counters and bit equality of the frames.
-    tools/ab_kernels.py CONFIG SPP KERNEL_A KERNEL_B [band]      e.g.  C3 8 5 6   |   C5 4 5 6 band   (W / H override the frame size, MAXB max_bounces, SCENE=axis:N[:mixed] the scene;
-    RTX_HIP_LIB selects another build of the library, see tools/build_variant.sh)"""
+"""Variants against each other on a BASELINE config (same box, same process): time, rates, counters and bit equality of the frames.
+    tools/ab_kernels.py CONFIG SPP SPEC [SPEC ...] [band]
+        SPEC = KERNEL[:TUNING]   KERNEL = RTX_KERNEL_* id, TUNING = RtxConfig.tuning bits (decimal or 0x..)
+        e.g.  C2 64 4 4:8 4:32      (two stages with packets | stage 1 per lane | one stage)
+              C3 8 5 6   |   C5 4 5 6 band
+    W / H override the frame size, MAXB max_bounces, SCENE=axis:N[:mixed] the scene, BLOCK the row block of the band;
+    RTX_HIP_LIB selects another build of the library (tools/build_variant.sh)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,8 +12,9 @@ import bench
 import rust_raytracing_amd as rtx
 from rust_raytracing_amd import scenes, tiles
 
-name, spp, ka, kb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-world = 8 if len(sys.argv) > 5 and sys.argv[5] == "band" else 1
+args = [a for a in sys.argv[1:] if a != "band"]
+name, spp, specs = args[0], int(args[1]), args[2:]
+world = 8 if "band" in sys.argv else 1
 cfg = bench.CONFIGS[name]
 objs = bench.make_objects(cfg)
 if os.environ.get("SCENE", "").startswith("axis"):                    # SCENE=axis:20000 -> 240k axis-aligned cube faces (+ SCENE=axis:20000:mixed: 2k spheres)
@@ -19,26 +24,30 @@ if os.environ.get("SCENE", "").startswith("axis"):                    # SCENE=ax
     if len(parts) > 2:
         objs = np.concatenate([objs, scenes.random_spheres(2000, 13)])
 w, h = int(os.environ.get("W", cfg["w"])), int(os.environ.get("H", cfg["h"]))
-rb, rs, n_rows = tiles.rows_for_rank(h, 0, world)
+block = int(os.environ.get("BLOCK", tiles.ROW_BLOCK))
+part = tiles.Partition(h, 0, world, block)
 dev = torch.device("cuda", 0)
 out = {}
-for k in (ka, kb):
-    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k, max_bounces=int(os.environ.get("MAXB", 10))), rtx.Camera(*scenes.CAMERA), objs).upload(0)
-    band = tiles.alloc_band(h, w, world, dev)
-    hnd.render_rows(w, h, rb, rs, n_rows, band.data_ptr())
+for spec in specs:
+    k, _, t = spec.partition(":")
+    k, t = int(k), int(t, 0) if t else 0
+    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k, tuning=t, max_bounces=int(os.environ.get("MAXB", 10))), rtx.Camera(*scenes.CAMERA), objs).upload(0)
+    band = part.alloc_band(w, dev)
+    part.render(hnd, w, band)
     torch.cuda.synchronize()
     ts = []
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
-        st = hnd.render_rows(w, h, rb, rs, n_rows, band.data_ptr())
+        st = part.render(hnd, w, band, want_stats=True)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    out[k] = band[:n_rows].clone()
-    rays = n_rows * w * spp
-    print("kernel %d (ran %d): %.2f ms  trace %.2f ms  %.1f Mrays/s  seg %d exact/seg %.3f box/seg %.1f launches %d" % (
-        k, st.kernel, min(ts) * 1e3, st.trace_ms, rays / min(ts) / 1e6, st.segments, st.exact_tests / max(st.segments, 1),
+    out[spec] = band[:part.n_rows].clone()
+    rays = part.n_rows * w * spp
+    print("%-8s (ran %d): %.2f ms  trace %.2f ms  %.1f Mrays/s  seg %d exact/seg %.3f box/seg %.1f launches %d" % (
+        spec, st.kernel, min(ts) * 1e3, st.trace_ms, rays / min(ts) / 1e6, st.segments, st.exact_tests / max(st.segments, 1),
         st.box_tests / max(st.segments, 1), st.trace_launches), flush=True)
     hnd.close()
-same = torch.equal(out[ka].view(torch.int64), out[kb].view(torch.int64))
+ref = out[specs[0]].view(torch.int64)
+same = all(torch.equal(ref, out[s].view(torch.int64)) for s in specs[1:])
 print("bit-identical:", same, flush=True)
 sys.exit(0 if same else 1)
