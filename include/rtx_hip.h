@@ -119,8 +119,11 @@ enum {
     RTX_TUNE_TWO_STAGE   = 1u << 6,  /* sphere trees: two stages even below 2^20 rays per launch */
     RTX_TUNE_BVH_MEDIAN  = 1u << 7,  /* tree build: median splits instead of the binned SAH */
     RTX_TUNE_TRI_LEAF_SHIFT = 8,     /* bits 8..11: triangles per leaf, 1..6 (0 = default: 5 pure footprint tree, 2 joint) */
-    RTX_TUNE_THRESH_SHIFT   = 12     /* bits 12..18: lanes that wait before the regrouping kernels' f64 phase runs, 1..64
+    RTX_TUNE_THRESH_SHIFT   = 12,    /* bits 12..18: lanes that wait before the regrouping kernels' f64 phase runs, 1..64
                                         (0 = default) */
+    RTX_TUNE_PK_LDS_STACK = 1u << 20, /* mesh packets: the wave-uniform stack in LDS (round 2) instead of in the lanes of a VGPR */
+    RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
+                                        their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };
 
 /* Camera (camera.rs:7-15).  to_world_space / to_cam_space are the three ROWS of each matrix
@@ -154,6 +157,12 @@ typedef struct RtxStats {
     uint64_t box_tests;          /* RTX_KERNEL_BVH only: ray/box slab tests (32 B node each) */
     uint32_t trace_launches;
     uint32_t kernel;             /* the RTX_KERNEL_* that ran (resolves RTX_KERNEL_AUTO) */
+    /* the two-stage form of RTX_KERNEL_BVH on a sphere tree (else 0): what its stage 1 -- the primary rays, one segment
+     * each -- accounts for of the totals above */
+    double   stage1_ms;
+    uint64_t stage1_box_tests;
+    uint64_t stage1_filter_tests;
+    uint64_t stage1_exact_tests;
 } RtxStats;
 
 typedef struct RtxSceneHandle_ *RtxSceneHandle;
@@ -173,8 +182,9 @@ RTX_STATIC_ASSERT(sizeof(RtxCamera) == 200 && offsetof(RtxCamera, position) == 8
                   offsetof(RtxCamera, to_cam_space) == 56 && offsetof(RtxCamera, to_world_space) == 128, "RtxCamera layout");
 RTX_STATIC_ASSERT(sizeof(RtxScene) == 272 && offsetof(RtxScene, camera) == 56 && offsetof(RtxScene, n_objects) == 256 &&
                   offsetof(RtxScene, objects) == 264, "RtxScene layout");
-RTX_STATIC_ASSERT(sizeof(RtxStats) == 72 && offsetof(RtxStats, trace_ms) == 32 && offsetof(RtxStats, box_tests) == 56 &&
-                  offsetof(RtxStats, trace_launches) == 64 && offsetof(RtxStats, kernel) == 68, "RtxStats layout");
+RTX_STATIC_ASSERT(sizeof(RtxStats) == 104 && offsetof(RtxStats, trace_ms) == 32 && offsetof(RtxStats, box_tests) == 56 &&
+                  offsetof(RtxStats, trace_launches) == 64 && offsetof(RtxStats, kernel) == 68 && offsetof(RtxStats, stage1_ms) == 72 &&
+                  offsetof(RtxStats, stage1_exact_tests) == 96, "RtxStats layout");
 
 /* -- library ----------------------------------------------------------------------------- */
 int32_t     rtx_version(void);

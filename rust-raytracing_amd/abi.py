@@ -18,6 +18,8 @@ RTX_KERNEL_WAVEFRONT = 6
 RTX_TUNE_NO_TILES, RTX_TUNE_BVH_CLASSIC, RTX_TUNE_NO_QNODES, RTX_TUNE_NO_PACKETS = 1, 2, 4, 8
 RTX_TUNE_WF_PURE, RTX_TUNE_ONE_STAGE, RTX_TUNE_TWO_STAGE, RTX_TUNE_BVH_MEDIAN = 16, 32, 64, 128
 RTX_TUNE_TRI_LEAF_SHIFT, RTX_TUNE_THRESH_SHIFT = 8, 12
+RTX_TUNE_SORT_SURVIVORS = 1 << 19
+RTX_TUNE_PK_LDS_STACK = 1 << 20
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)
@@ -47,7 +49,9 @@ class RtxStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("segments", C.c_uint64), ("exact_tests", C.c_uint64),
                 ("filter_tests", C.c_uint64), ("trace_ms", C.c_double), ("resolve_ms", C.c_double),
                 ("filter_mismatches", C.c_uint64), ("box_tests", C.c_uint64),
-                ("trace_launches", C.c_uint32), ("kernel", C.c_uint32)]
+                ("trace_launches", C.c_uint32), ("kernel", C.c_uint32),
+                ("stage1_ms", C.c_double), ("stage1_box_tests", C.c_uint64), ("stage1_filter_tests", C.c_uint64),
+                ("stage1_exact_tests", C.c_uint64)]
 
 
 # every symbol include/rtx_hip.h declares: (name, restype, argtypes)

@@ -94,7 +94,8 @@ struct RtxSceneHandle_ {
     unsigned long long *work_counter = nullptr;
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
     RowsView *d_rv = nullptr;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };      // [3]: the end of the sphere kernel's stage 1 (stats only)
+    Counters *counters_stage1 = nullptr;                   // the counters as stage 1 left them (stats only)
     // The handle's device buffers (descriptors, tables, counters, scratch) are shared by all of its renders, so they
     // are ordered on ONE stream at a time: when a call brings a different stream the previous one is drained first.
     size_t scratch_limit = 0;                             // rtx_scene_set_scratch_limit (0 = default)
@@ -173,6 +174,7 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->state) (void)hipFree(h->state);
     if (h->wf_state) (void)hipFree(h->wf_state);
     if (h->counters) (void)hipFree(h->counters);
+    if (h->counters_stage1) (void)hipFree(h->counters_stage1);
     if (h->work_counter) (void)hipFree(h->work_counter);
     if (h->d_sv) (void)hipFree(h->d_sv);
     if (h->d_rv) (void)hipFree(h->d_rv);
@@ -497,6 +499,7 @@ int32_t create_handle(const RtxScene *scene, const PackedScene &p, int32_t devic
     h->objects.assign(scene->objects, scene->objects + scene->n_objects);
 
     hipError_t e = hipMalloc((void **)&h->counters, sizeof(Counters) * kCounterShards);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->counters_stage1, sizeof(Counters) * kCounterShards);
     if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_sv, sizeof(SceneView));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_rv, sizeof(RowsView));
@@ -736,7 +739,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         // (+ the survivors' queue of the sphere kernel's two-stage form, 64 B)
         const bool sph2 = kernel == RTX_KERNEL_BVH && (h->sv.bvh_flags & 2u) == 0u && h->sv.n_bvh_nodes != 0;
         const uint64_t per_ray = 4 * sizeof(double) + (kernel == RTX_KERNEL_WAVEFRONT ? wavefront_state_bytes(1u << 20, 1) >> 20 : 0) +
-                                 (sph2 ? 64 : 0);
+                                 (sph2 ? 64 + 5 : 0);
         // the cap: the handle's limit, never more than 3/4 of what is free on the device now (other handles, ranks or
         // frameworks may share it; what this handle already holds counts as free for it)
         size_t cap_bytes = h->scratch_limit ? h->scratch_limit : kDefaultScratchBytes;
@@ -836,7 +839,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         h->sv_dirty = false;
     }
     RTX_HIP_CHECK(hipMemsetAsync(h->counters, 0, sizeof(Counters) * kCounterShards, stream));
-    float trace_ms = 0.f, resolve_ms = 0.f;
+    float trace_ms = 0.f, resolve_ms = 0.f, stage1_ms = 0.f;
+    unsigned long long s1_exact = 0, s1_filter = 0, s1_box = 0, prev_exact = 0, prev_filter = 0, prev_box = 0;
     uint32_t launches = 0;
 
     if (spp == 0) {
@@ -882,7 +886,9 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                 RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus,
                                                        spheres_two_stage ? h->wf_state : nullptr,
-                                                       (tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u, stream));
+                                                       ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u), stream,
+                                                       stats && spheres_two_stage ? h->counters_stage1 : nullptr,
+                                                       stats && spheres_two_stage ? h->ev[3] : nullptr));
             else
                 RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
@@ -901,6 +907,23 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
             RTX_HIP_CHECK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
             RTX_HIP_CHECK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
             trace_ms += a; resolve_ms += b;
+            if (spheres_two_stage) {                        // stage 1's share of this batch (launch_trace_bvh_spheres recorded ev[3], took the snapshot)
+                float c = 0.f;
+                RTX_HIP_CHECK(hipEventElapsedTime(&c, h->ev[0], h->ev[3]));
+                stage1_ms += c;
+                Counters s1[kCounterShards];
+                RTX_HIP_CHECK(hipMemcpy(s1, h->counters_stage1, sizeof s1, hipMemcpyDeviceToHost));
+                // (the counters accumulate over the batches of a call: the snapshot holds batches 0..k-1 in full + stage 1 of
+                //  batch k, the previous totals are subtracted below)
+                unsigned long long e1 = 0, f1 = 0, b1 = 0;
+                for (int k = 0; k < kCounterShards; ++k) { e1 += s1[k].exact_tests; f1 += s1[k].filter_tests; if (k >= 2) b1 += s1[k].pad_; }
+                Counters now[kCounterShards];
+                RTX_HIP_CHECK(hipMemcpy(now, h->counters, sizeof now, hipMemcpyDeviceToHost));
+                unsigned long long e2 = 0, f2 = 0, b2 = 0;
+                for (int k = 0; k < kCounterShards; ++k) { e2 += now[k].exact_tests; f2 += now[k].filter_tests; if (k >= 2) b2 += now[k].pad_; }
+                s1_exact += e1 - prev_exact; s1_filter += f1 - prev_filter; s1_box += b1 - prev_box;
+                prev_exact = e2; prev_filter = f2; prev_box = b2;
+            }
         }
     }
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY || spheres_two_stage) {
@@ -936,6 +959,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         stats->resolve_ms = resolve_ms;
         stats->trace_launches = launches;
         stats->kernel = kernel;                       // the kernel that actually ran (RTX_KERNEL_*)
+        stats->stage1_ms = stage1_ms;
+        stats->stage1_box_tests = s1_box; stats->stage1_filter_tests = s1_filter; stats->stage1_exact_tests = s1_exact;
     }
     return RTX_OK;
 }

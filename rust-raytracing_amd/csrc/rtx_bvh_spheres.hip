@@ -16,6 +16,8 @@
 #include "rtx_launch.h"
 #include "rtx_traverse.h"
 
+#include <cmath>
+
 namespace rtx {
 
 constexpr int kSphWavesPerSimd = 4;          // = workgroups per CU (4 waves each)
@@ -42,6 +44,7 @@ struct SphSurvivor {
 static_assert(sizeof(SphSurvivor) == 64, "SphSurvivor must be one 64-byte line");
 struct SphQueue {
     SphSurvivor *rec;
+    const uint32_t *perm;                     // stage 2 reads rec[perm[k]] (the survivors ordered by sph_sort_*), or null: queue order
     unsigned long long *count;                // slots reserved by stage 1 = the length stage 2 walks
     unsigned long long capacity;
 };
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                 if constexpr (MODE == 2) {
                     double4 s0 = make_double4(0., 0., 0., 0.), s1 = s0;
                     if (valid) {                           // a ray in flight, as stage 1 left it after its first hit
-                        const double4 *p = reinterpret_cast<const double4 *>(sq.rec + my);
+                        const double4 *p = reinterpret_cast<const double4 *>(sq.rec + (sq.perm ? (unsigned long long)sq.perm[my] : my));
                         s0 = p[0]; s1 = p[1];
                         ridx = (uint32_t)(unsigned long long)__double_as_longlong(s1.z);
                         valid = ridx != kNone;
@@ -303,6 +306,7 @@ constexpr int kSpkStack = 63;                // wave-uniform stack entries: the 
 #endif
 constexpr int kSpkWaves = RTX_SPK_WAVES;     // workgroups per CU
 constexpr uint32_t kSphNoPackets = 1u;       // launch flag: stage 1 per lane (A/B runs)
+constexpr uint32_t kSphSortSurvivors = 2u;   // launch flag: stage 2 reads the survivors ordered by exit distance and octant
 
 // The walk of one tile.  SGN < 8: every ray of the tile points into octant SGN (bit a set: direction component a is
 // negative), so the near / far plane of each slab is known at compile time; SGN == 8: mixed signs, min / max per slab.
@@ -597,6 +601,103 @@ __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kerne
     }
 }
 
+// ---- ordering the survivors for stage 2 ----------------------------------------------------------------------------------
+// A wave's round lasts as long as its longest walk, and how long a walk is depends mostly on how far the ray travels inside
+// the cloud.  The survivors are therefore binned by the distance at which their ray leaves the scene's box (kSortT bins) and
+// the octant of their direction, with a counting sort over the queue: histogram (keys kept), scan, scatter of the record
+// indices.  Within a bin the queue's tile order is kept up to the arrival order of the workgroups.
+constexpr int kSortT = 32, kSortBins = kSortT * 8;
+struct SphSort {
+    uint8_t *key;               // per queue slot
+    uint32_t *perm;             // sorted position -> queue slot
+    unsigned int *hist;         // [kSortBins] counts, then running offsets
+    float lo[3], hi[3], inv_dt; // the scene's box (sphere centre -+ reach) and kSortT / its diagonal
+};
+
+__device__ __forceinline__ uint32_t sph_sort_key(const SphSort &so, const SphSurvivor &r)
+{
+    if (r.ridx == kNone) return (uint32_t)kSortBins - 1u;                      // a dead slot: to the very end
+    const float px = (float)r.px, py = (float)r.py, pz = (float)r.pz, dx = (float)r.dx, dy = (float)r.dy, dz = (float)r.dz;
+    const float tx = ((dx > 0.f ? so.hi[0] : so.lo[0]) - px) / dx, ty = ((dy > 0.f ? so.hi[1] : so.lo[1]) - py) / dy,
+                tz = ((dz > 0.f ? so.hi[2] : so.lo[2]) - pz) / dz;
+    float t = fminf(fminf(tx, ty), tz) * so.inv_dt;                               // (NaN / inf operands: any bin will do)
+    t = t >= 0.f ? t : 0.f;
+    const uint32_t tb = t < (float)(kSortT - 1) ? (uint32_t)t : (uint32_t)(kSortT - 1);
+    const uint32_t oct = (dx < 0.f ? 1u : 0u) | (dy < 0.f ? 2u : 0u) | (dz < 0.f ? 4u : 0u);
+#ifndef RTX_SORT_MODE
+#define RTX_SORT_MODE 0
+#endif
+#if RTX_SORT_MODE == 1
+    uint32_t k = oct;                                                             // direction octant alone (tile order within it)
+    (void)tb;
+#elif RTX_SORT_MODE == 2
+    // the cell of the ray's origin (2 x 4 x 4 over the scene's box) and the octant
+    const float fx = (px - so.lo[0]) / (so.hi[0] - so.lo[0]), fy = (py - so.lo[1]) / (so.hi[1] - so.lo[1]), fz = (pz - so.lo[2]) / (so.hi[2] - so.lo[2]);
+    const uint32_t cx = fx > 0.5f ? 1u : 0u, cy = fy <= 0.f ? 0u : (fy >= 1.f ? 3u : (uint32_t)(fy * 4.f)), cz = fz <= 0.f ? 0u : (fz >= 1.f ? 3u : (uint32_t)(fz * 4.f));
+    uint32_t k = ((cx * 4u + cy) * 4u + cz) * 8u + oct;
+    (void)tb;
+#else
+    uint32_t k = tb * 8u + oct;
+#endif
+    return k < (uint32_t)kSortBins - 1u ? k : (uint32_t)kSortBins - 2u;
+}
+
+__global__ __launch_bounds__(256) void sph_sort_hist_kernel(const SphQueue sq, const SphSort so)
+{
+    __shared__ unsigned int h[kSortBins];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned long long n = *sq.count < sq.capacity ? *sq.count : sq.capacity;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const uint32_t k = sph_sort_key(so, sq.rec[i]);
+        so.key[i] = (uint8_t)k;
+        atomicAdd(&h[k], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&so.hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void sph_sort_scan_kernel(const SphSort so)          // one workgroup: counts -> first positions
+{
+    __shared__ unsigned int h[kSortBins];
+    h[threadIdx.x] = so.hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int k = 0; k < kSortBins; ++k) { const unsigned int c = h[k]; h[k] = run; run += c; }
+    }
+    __syncthreads();
+    so.hist[threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void sph_sort_scatter_kernel(const SphQueue sq, const SphSort so)
+{
+    __shared__ unsigned int cnt[kSortBins], base[kSortBins];
+    const unsigned long long n = *sq.count < sq.capacity ? *sq.count : sq.capacity;
+    // a workgroup takes chunks of 4096 consecutive slots: one reservation per (chunk, bin)
+    constexpr unsigned long long kChunk = 4096;
+    for (unsigned long long c0 = (unsigned long long)blockIdx.x * kChunk; c0 < n; c0 += (unsigned long long)gridDim.x * kChunk) {
+        cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t rank[kChunk / 256], key[kChunk / 256];
+#pragma unroll
+        for (int j = 0; j < (int)(kChunk / 256); ++j) {
+            const unsigned long long i = c0 + (unsigned long long)j * 256u + threadIdx.x;
+            key[j] = i < n ? (uint32_t)so.key[i] : 0xFFFFFFFFu;
+            rank[j] = key[j] != 0xFFFFFFFFu ? atomicAdd(&cnt[key[j]], 1u) : 0u;
+        }
+        __syncthreads();
+        base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&so.hist[threadIdx.x], cnt[threadIdx.x]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (int)(kChunk / 256); ++j) {
+            const unsigned long long i = c0 + (unsigned long long)j * 256u + threadIdx.x;
+            if (key[j] != 0xFFFFFFFFu) so.perm[base[key[j]] + rank[j]] = (uint32_t)i;
+        }
+        __syncthreads();
+    }
+}
+
 uint32_t bvh_spheres_spill_entries(const SceneView &sv)
 {
     const uint32_t need = 3u * sv.bvh_depth + 2u;       // a 4-wide node pushes at most 3 entries per level
@@ -619,7 +720,7 @@ static uint64_t sph_queue_capacity(uint64_t n_rays, int n_cus)
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus)
 {
     const uint64_t cap = sph_queue_capacity(n_rays, n_cus);
-    return (size_t)(cap * sizeof(SphSurvivor) + 2 * 256);
+    return (size_t)(cap * sizeof(SphSurvivor) + 2 * 256) + (size_t)((cap * 5 + 255) & ~(uint64_t)255) + 4 * 256 + 256;   // + the sort's keys, permutation, histogram
 }
 
 // may stage 1 walk as packets?  The ray queue in 8x8 tiles and a tree the wave-uniform stack holds.
@@ -630,7 +731,7 @@ static bool sph_packets_ok(const SceneView &sv, const RowsView &rv)
 
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    void *queue_mem, uint32_t flags, hipStream_t stream)
+                                    void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot, hipEvent_t stage1_done)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -669,6 +770,29 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                            spill_entries, sq);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (stage1_snapshot && (e = hipMemcpyAsync(stage1_snapshot, counters, sizeof(Counters) * kCounterShards, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+    if (stage1_done && (e = hipEventRecord(stage1_done, stream)) != hipSuccess) return e;
+    if (flags & kSphSortSurvivors) {
+        SphSort so{};
+        char *q = p + 256 + capacity * sizeof(SphSurvivor);
+        q = reinterpret_cast<char *>(((uintptr_t)q + 255) & ~(uintptr_t)255);
+        so.hist = reinterpret_cast<unsigned int *>(q);
+        so.perm = reinterpret_cast<uint32_t *>(q + 4 * 256);
+        so.key = reinterpret_cast<uint8_t *>(so.perm + capacity);
+        double diag2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            so.lo[a] = (float)(sv.sphere_center[a] - sv.sphere_cmax); so.hi[a] = (float)(sv.sphere_center[a] + sv.sphere_cmax);
+            diag2 += 4.0 * sv.sphere_cmax * sv.sphere_cmax;
+        }
+        so.inv_dt = diag2 > 0.0 ? (float)(kSortT / (0.6 * std::sqrt(diag2))) : 0.f;
+        if ((e = hipMemsetAsync(so.hist, 0, kSortBins * sizeof(unsigned int), stream)) != hipSuccess) return e;
+        const uint32_t sblocks = (uint32_t)n_cus * 8u;
+        hipLaunchKernelGGL(sph_sort_hist_kernel, dim3(sblocks), dim3(256), 0, stream, sq, so);
+        hipLaunchKernelGGL(sph_sort_scan_kernel, dim3(1), dim3(256), 0, stream, so);
+        hipLaunchKernelGGL(sph_sort_scatter_kernel, dim3(sblocks), dim3(256), 0, stream, sq, so);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        sq.perm = so.perm;
+    }
     auto k2 = deep ? trace_bvh_spheres_kernel<true, 2> : trace_bvh_spheres_kernel<false, 2>;
     hipLaunchKernelGGL(k2, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, nodes, la, spill,
                        spill_entries, sq);

@@ -40,7 +40,10 @@ size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    void *queue_mem, uint32_t flags, hipStream_t stream);
+                                    void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot = nullptr,
+                                    hipEvent_t stage1_done = nullptr);
+// (stage1_snapshot: kCounterShards Counters that receive a copy of `counters` as stage 1 left them; stage1_done: recorded
+// after stage 1 -- both only for the two-stage form, both optional: what RtxStats' stage1_* fields are made of)
 
 // RTX_KERNEL_BVH_REGROUP for trees that hold spheres only (rtx_bvh_spheres_pool.hip): every lane owns a pool of rays, the
 // f64 phase serves all of them, the walk runs the lane's pending segments one after the other with the waiting lanes

@@ -9,7 +9,7 @@
 
 namespace rtx {
 
-constexpr uint32_t kWfFallback = 0x80000000u;                     // cand.count flag: the shade kernel walks this ray itself
+constexpr uint32_t kWfFallback = 0x80000000u;                     // cand.count flag: no f32 walk could finish this ray (origin out of any range, a full overflow list): the shade kernel tests every shape exactly
 constexpr uint32_t kWfDead = 0x40000000u;                         // cand.count flag: no ray in this queue slot (the padding of partial tiles)
 constexpr uint32_t kWfExtra = 0x20000000u;                        // cand.count flag: more candidates of this ray are in the level's overflow list
 constexpr uint32_t kWfExtraCap = 1u << 16;                        // entries of that list (a handful per frame are used: C3 11 rays, C5 33)
@@ -85,7 +85,13 @@ __device__ __forceinline__ bool wf_flush_to_extra(const WfState &st, uint32_t po
     for (int e = 0; e < queue; ++e)
         if ((uint32_t)e < qcnt && __uint_as_float(lds_q[(size_t)(queue + e) * kBvhThreads + tid]) <= best_up) live += 1;
     const unsigned long long base = atomicAdd(st.xcount, (unsigned long long)live);
-    if (base + live > (unsigned long long)kWfExtraCap) return false;
+    if (base + live > (unsigned long long)kWfExtraCap) {
+        // the list is full.  The shade kernel scans entries [0, min(xcount, cap)): what this reservation covers of that range
+        // stays unwritten by any flush, so it is marked as nobody's (the list is not cleared between levels or launches: a
+        // stale entry could name a live queue position, an unwritten one index a null array)
+        for (unsigned long long k = base; k < (unsigned long long)kWfExtraCap && k < base + live; ++k) st.extra[k] = make_uint2(kNone, 0u);
+        return false;
+    }
     uint32_t k = 0;
     for (int e = 0; e < queue; ++e) {
         if ((uint32_t)e < qcnt && __uint_as_float(lds_q[(size_t)(queue + e) * kBvhThreads + tid]) <= best_up) {

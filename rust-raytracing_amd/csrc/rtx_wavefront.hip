@@ -17,9 +17,9 @@
 // state + 64 B record + 32 B candidates, read and written: ~400 B per segment) -- the "SoA rays in HBM + ballot / prefix
 // sum compaction" of BASELINE.json's north star, and for the first time a visible share of the HBM roofline.
 //
-// A ray the walk cannot finish in f32 -- origin outside the tree's range, more live candidates than the queue holds --
-// is flagged and the shade kernel walks it itself with round 1's step (bvh_traverse: exact tests interleaved), or tests
-// every shape when even the f64 slab test is out of range.
+// A walk whose 6-entry candidate queue runs full moves its live entries to the level's overflow list (wf_flush_to_extra) and
+// goes on; a far origin walks with Ray32S's slack.  What no f32 walk can finish -- an origin beyond 2^27 x origin_limit or
+// NaN, a full overflow list -- is flagged kWfFallback and the shade kernel tests every shape exactly for that segment.
 #include "rtx_launch.h"
 #include "rtx_mesh_step.h"
 #include "rtx_wavefront.h"
@@ -227,13 +227,30 @@ constexpr int kPkWavesJoint = RTX_PK_WAVES_JOINT;
 
 // (PkConst4 / pk_const / pk_bits: wave-uniform reads through the scalar cache, rtx_traverse.h)
 
+// v_writelane_b32 (this clang has no __builtin_amdgcn_writelane; the LLVM intrinsic is reached by its name)
+extern "C" __device__ int rtx_wf_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// The wave-uniform stack of a packet walk in the lanes of ONE VGPR (v_writelane / v_readlane with a scalar index) when the
+// tree's depth allows it (3 * depth + 2 <= kPkLaneStack), else in LDS (lane 0 stores, exec-masked).  The packet kernels are
+// SCALAR-pipe bound (C3: 1.06e10 SALU instructions per launch against 0.95e10 VALU, one scalar pipe per CU ~80 % busy,
+// profiles/r03_mesh_packets_pmc.txt), and an LDS push costs 6 scalar instructions of exec handling where the register push
+// costs 2.  (Measured and dropped here: the sphere packets' full treatment -- one loop instance per direction quadrant, the
+// leaf code once behind scalar selects -- issued MORE instructions on a mesh, whose walk is dominated by leaf records
+// (705 per tile against 369 node visits on C3): 39.8 against 34.2 ms; RTX_TUNE_PK_LDS_STACK keeps the LDS form for A/B.)
+constexpr int kPkLaneStack = 63;
+#ifdef RTX_PK_OLD_BALLOT
+#define RTX_PK_BALLOT(x) __ballot(x)
+#else
+#define RTX_PK_BALLOT(x) __builtin_amdgcn_ballot_w64(x)          // the mask straight out of v_cmp (HIP's __ballot re-materialises the bool: 2 more VALU)
+#endif
+
 // PLAIN 1: every node is a footprint node, every leaf a triangle leaf (C3, C5).  PLAIN 0: a joint tree -- 3-D nodes over
 // sphere boxes and the footprints of the other planes, the (x, y) footprint sub-tree behind links with kBvhFlatNode, sphere
 // leaves with bvh_traverse_spheres' bounds (cmax_ru: SceneView::sphere_cmax rounded up, for their error terms).
 template <int PLAIN>
 __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void wf_trace_packet_kernel(const WfState st, Counters *__restrict__ ctr,
                                                                                 const float4 *__restrict__ nodes, const MeshArrays ma,
-                                                                                uint32_t root, float cmax_ru)
+                                                                                uint32_t root, float cmax_ru, uint32_t lane_stack)
 {
     __shared__ uint32_t pk_stack[kBvhThreads >> 6][kPkStack];
     __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];
@@ -293,6 +310,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
             }
         }
 
+        int stk_v = 0;                                              // the lane-stack form of the wave's stack
         while (node != kNone) {
             // the node's bytes at a wave-uniform address.  A footprint node: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
             // (96 bytes); a 3-D node of a joint tree: 4 x {lo.xyz, link}, 4 x {hi.xyz, count}
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const bool in = tc[c] < __builtin_inff();
-                const unsigned long long hm = __ballot(in);
+                const unsigned long long hm = RTX_PK_BALLOT(in);
                 key[c] = 0x7F800000u;
                 kl[c] = PLAIN ? (lnk[c] & ~kBvhFlatNode) : lnk[c];
                 if (hm == 0ull || cnt[c] == 0xFFFFFFFFu) continue;
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
                     const PkConst4 rp = ctri + 2 * (size_t)(first + j);
                     const float4 A = rp[0], B = rp[1];
                     const bool pass = in && (int)tri_filter_sign(A, B, tp) >= 0;
-                    if (__ballot(pass) == 0ull) continue;
+                    if (RTX_PK_BALLOT(pass) == 0ull) continue;
                     const PkConst4 gp = cgeo + 2 * (size_t)(first + j);
                     const float4 g0 = gp[0], g1 = gp[1];
                     if (pass) {
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
                             best_up = fminf(best_up, thi);
                             if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {       // more live candidates than the queue holds:
                                 if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;   // to the overflow list
-                                else { overflow = true; best_up = -__builtin_inff(); }     // (full: the shade kernel walks this ray)
+                                else { overflow = true; best_up = -__builtin_inff(); }     // (full: the shade kernel tests every shape for this ray)
                             }
                             if (!overflow) {
                                 lq[(size_t)qcnt * kBvhThreads + tid] = (first + j) | kQueueTri;
@@ -391,13 +409,20 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
 #define RTX_CSWAP(i, j) { if (key[j] < key[i]) { uint32_t tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = kl[i]; kl[i] = kl[j]; kl[j] = tl; } }
             RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
-            if (key[3] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[3]; sp += 1; }
-            if (key[2] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[2]; sp += 1; }
-            if (key[1] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[1]; sp += 1; }
+            if (lane_stack) {
+                // three unconditional pushes, farthest first; an invalid one lands on the slot the next push overwrites
+                stk_v = rtx_wf_writelane((int)kl[3], (int)sp, stk_v); sp += key[3] < 0x7F800000u ? 1u : 0u;
+                stk_v = rtx_wf_writelane((int)kl[2], (int)sp, stk_v); sp += key[2] < 0x7F800000u ? 1u : 0u;
+                stk_v = rtx_wf_writelane((int)kl[1], (int)sp, stk_v); sp += key[1] < 0x7F800000u ? 1u : 0u;
+            } else {
+                if (key[3] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[3]; sp += 1; }
+                if (key[2] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[2]; sp += 1; }
+                if (key[1] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[1]; sp += 1; }
+            }
             node = key[0] < 0x7F800000u ? kl[0] : kNone;
             if (node == kNone && sp != 0u) {
                 sp -= 1;
-                node = __builtin_amdgcn_readfirstlane(stk[sp]);
+                node = lane_stack ? (uint32_t)__builtin_amdgcn_readlane(stk_v, (int)sp) : __builtin_amdgcn_readfirstlane(stk[sp]);
             }
         }
         if (p < n_queue) {
@@ -667,8 +692,9 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * (joint ? kPkWavesJoint : kPkWaves));
     auto level_fn = [&](const WfState &sk, uint32_t level) {
         if (level == 0u && packets) {
-            if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru);
-            else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru);
+            const uint32_t lane_stack = 3u * sv.bvh_depth + 2u <= (uint32_t)kPkLaneStack && (sv.tuning & RTX_TUNE_PK_LDS_STACK) == 0u ? 1u : 0u;
+            if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
+            else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
         } else if (qn) {
             if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);
             else hipLaunchKernelGGL((wf_trace_kernel<false, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);

@@ -56,7 +56,7 @@ pub struct RtxScene {
     pub objects: *const RtxObject,
 }
 
-/// Counters of one `rtx_render_rows` call.  72 bytes.
+/// Counters of one `rtx_render_rows` call.  104 bytes.
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct RtxStats {
@@ -70,6 +70,10 @@ pub struct RtxStats {
     pub box_tests: u64,
     pub trace_launches: u32,
     pub kernel: u32,
+    pub stage1_ms: f64,
+    pub stage1_box_tests: u64,
+    pub stage1_filter_tests: u64,
+    pub stage1_exact_tests: u64,
 }
 
 #[repr(C)]

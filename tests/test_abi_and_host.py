@@ -326,9 +326,11 @@ def test_bvh_invariants_on_awkward_and_random_scenes(rtx):
 
 
 def test_bench_roofline_object_is_a_fraction_of_a_real_ceiling(tmp_path, monkeypatch):
-    """bench.py's roofline arithmetic on synthetic counts (no GPU): frac = lane-ops issued / launch time / VALU peak,
-    hbm_frac = (2 x FETCH + WRITE) / launch time / 8 TB/s, both <= 1 for round 1's measured counters; a counter file is
-    refused when it was measured on other kernel sources."""
+    """bench.py's roofline arithmetic on synthetic counts (no GPU): ONE scale (lane-instructions against the VALU peak) with
+    frac = the USEFUL fraction (the tests the kernel counted x LANE_OPS) <= issued.frac (SQ_THREAD_CYCLES_VALU), the identity
+    issued.frac = valu_busy x lane_utilisation x 2 / valu_cycles_per_instruction, hbm_frac = (2 x FETCH + WRITE) / launch
+    time / 8 TB/s, the two stages of the sphere kernel reported separately and adding up; the LDS sweep's packed filter
+    priced so that useful <= issued there too; a counter file is refused when it was measured on other kernel sources."""
     import importlib.util
     import json
     spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
@@ -336,29 +338,55 @@ def test_bench_roofline_object_is_a_fraction_of_a_real_ceiling(tmp_path, monkeyp
     spec.loader.exec_module(b)
     acc = b.Acc()
 
-    class St:                                   # round 1, C2 at 64 spp, one launch of trace_bvh_kernel<false,false>
-        trace_ms = 94.78; segments = 280450000; filter_tests = int(280450000 * 97.6); exact_tests = int(280450000 * 1.2)
-        box_tests = int(280450000 * 96.0); trace_launches = 1; kernel = 4
+    class St:                                   # round 2's C2 launch, split as round 3's stats report it
+        trace_ms = 81.3; segments = 280452564; filter_tests = int(280452564 * 95.05); exact_tests = int(280452564 * 0.566)
+        box_tests = int(280452564 * 93.45); trace_launches = 1; kernel = 4; primary_rays = 1920 * 1080 * 64
+        stage1_ms = 25.3; stage1_box_tests = 132710400 * 100; stage1_filter_tests = 132710400 * 101; stage1_exact_tests = 132710400 // 2
     acc.add(St)
-    counters = {"SQ_THREAD_CYCLES_VALU": 1.639e11 * 8, "SQ_ACTIVE_INST_VALU": 5.557e9 * 8, "SQ_INSTS_VALU": 5.474e9 * 8,
-                "FETCH_SIZE": 13218599.7, "WRITE_SIZE": 9146993.3}
-    r = b.roofline_of(acc, b.CONFIGS["C2"], counters, "test")
-    assert r["bound"] == "valu" and 0.1 < r["frac"] < 0.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["lane_utilisation"] - 0.46) < 0.01 and 0.5 < r["valu_busy"] < 1.0
-    assert abs(r["traffic"] - (2 * 13218599.7 + 9146993.3) * 1024) < 1 and 0.03 < r["hbm_frac"] < 0.06
-    assert 0 < r["algorithmic"]["frac_of_valu_peak"] < r["frac"]          # the minimal op count is below what was issued
-    assert abs(r["algorithmic"]["bytes_per_segment"] - (96 * 32 + 1.6 * 16 + 1.2 * 32)) < 1.0
+    counters = {"SQ_THREAD_CYCLES_VALU": 1.3347e12, "SQ_ACTIVE_INST_VALU": 4.0188e10, "SQ_INSTS_VALU": 3.9665e10,
+                "SQ_INSTS_SALU": 1.0e10, "SQ_WAVE_CYCLES": 1.9577e11, "SQ_WAIT_ANY": 1.0707e11,
+                "FETCH_SIZE": 16316652.5, "WRITE_SIZE": 14350844.6}
+    per = {"trace_sph_packet_kernel": {"SQ_THREAD_CYCLES_VALU": 4.5e11, "SQ_ACTIVE_INST_VALU": 8.5e9, "SQ_INSTS_VALU": 8.0e9, "_ms": 25.0, "_calls": 1.0},
+           "trace_bvh_spheres_kernel<false, 2>": {"SQ_THREAD_CYCLES_VALU": 6.3e11, "SQ_ACTIVE_INST_VALU": 2.566e10, "SQ_INSTS_VALU": 2.535e10, "_ms": 56.0, "_calls": 1.0}}
+    r = b.roofline_of(acc, b.CONFIGS["C2"], counters, "test", per)
+    assert r["bound"] == "valu" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["frac"] == r["algorithmic"]["frac_of_valu_peak"] and 0.05 < r["frac"] < r["issued"]["frac"] < 0.3     # useful <= issued
+    assert abs(r["lane_utilisation"] - 0.526) < 0.01 and 0.5 < r["valu_busy"] < 1.0
+    ident = r["valu_busy"] * r["lane_utilisation"] * 2.0 / r["valu_cycles_per_instruction"]
+    assert abs(ident - r["issued"]["frac"]) < 1e-9                                  # the stated identity holds
+    assert abs(r["traffic"] - (2 * 16316652.5 + 14350844.6) * 1024) < 1 and 0.05 < r["hbm_frac"] < 0.1
+    assert abs(r["algorithmic"]["bytes_per_segment"] - (93.45 * 32 + 1.6 * 16 + 0.566 * 32)) < 1.0
+    st = r["stages"]
+    assert len(st) == 2 and abs(st[0]["ms"] + st[1]["ms"] - 81.3) < 1e-9 and abs(st[0]["segments"] + st[1]["segments"] - 280452564) < 1
+    assert st[0]["kernel"] == "trace_sph_packet_kernel" and st[1]["kernel"].endswith("<false, 2>")
+    assert all(0 < s_["frac"] < s_["issued_frac"] for s_ in st)
+    assert [k["kernel"] for k in r["kernels"]] == ["trace_bvh_spheres_kernel<false, 2>", "trace_sph_packet_kernel"]
     r0 = b.roofline_of(acc, b.CONFIGS["C2"], None, "none")
-    assert r0["traffic"] is None and r0["hbm_frac"] is None and 0 < r0["frac"] <= 1 and "algorithmic" in r0["frac_source"]
+    assert r0["traffic"] is None and r0["hbm_frac"] is None and r0["issued"] is None and 0 < r0["frac"] <= 1 and "useful" in r0["frac_source"]
+    # the LDS sweep: 10^4 packed filter evaluations per segment priced at 4 lane-instructions -> useful below issued
+    sweep = b.Acc()
+
+    class Sw:
+        trace_ms = 440.0; segments = 280452564; filter_tests = 280452564 * 10124; exact_tests = int(280452564 * 1.9)
+        box_tests = 0; trace_launches = 1; kernel = 2; primary_rays = 1920 * 1080 * 64
+        stage1_ms = 0.0; stage1_box_tests = 0; stage1_filter_tests = 0; stage1_exact_tests = 0
+    sweep.add(Sw)
+    rs = b.roofline_of(sweep, b.CONFIGS["C2"], {"SQ_THREAD_CYCLES_VALU": 0.383 * 78.6432e12 * 0.44, "SQ_ACTIVE_INST_VALU": 0.383 * 78.6432e12 * 0.44 / 62.0,
+                                                "SQ_INSTS_VALU": 0.383 * 78.6432e12 * 0.44 / 62.0}, "test")
+    assert 0.2 < rs["frac"] < rs["issued"]["frac"] < 0.5
     # stored counters: refused for other sources, accepted for this tree
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
     os.makedirs(tmp_path / "rust-raytracing_amd" / "csrc")
     (tmp_path / "rust-raytracing_amd" / "csrc" / "k.hip").write_text("kernel v1")
-    json.dump({"kernel_source_hash": b.kernel_source_hash(), "collected": "t", "legs": {"C2:64:full:0": counters}},
+    json.dump({"kernel_source_hash": b.kernel_source_hash(), "collected": "t", "legs": {"C2:64:full:0": counters},
+               "legs_per_kernel": {"C2:64:full:0": per}},
               open(tmp_path / "profiles" / "pmc_counters.json", "w"))
-    got, src = b.stored_counters("C2:64:full:0")
-    assert got == counters and "pmc_counters.json" in src
+    got, gper, src = b.stored_counters("C2:64:full:0")
+    assert got == counters and gper == per and "pmc_counters.json" in src
     (tmp_path / "rust-raytracing_amd" / "csrc" / "k.hip").write_text("kernel v2")
-    got, src = b.stored_counters("C2:64:full:0")
+    got, gper, src = b.stored_counters("C2:64:full:0")
     assert got is None and "other kernel sources" in src
+    # the CPU baseline states the parallelism it may use: min(affinity, cgroup quota)
+    n, how, quota = b.cpu_threads_available()
+    assert n >= 1 and "sched_getaffinity" in how

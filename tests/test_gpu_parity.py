@@ -105,6 +105,51 @@ def test_mixed_kernel_is_bit_identical_to_exact_kernel(gpu):
     assert c[3] < a[3] / 50 and c[4] > 0
 
 
+# ---- values that follow from the reference's text alone: no oracle involved -------------------------------------------
+def test_closed_form_values_pin_the_device_path(gpu):
+    """tests/closed_form.py: scenes whose pixels the reference's TEXT determines exactly -- a closed box where every sample is
+    sum 2^-k (scene.rs:227, :276-277, plane.rs:25), the camera inside a sphere (sphere.rs:29, scene.rs:249: black), and
+    SURVEY 8c's triangle distances 5.0 / 5.0 (phantom) / 5.007244751357777 (phantom) bracketed to 1e-9 through
+    closest_object's ordering -- for every kernel, with no oracle in the loop."""
+    import closed_form as cf
+    dt = gpu.OBJECT_DTYPE
+    cam = ((0.3, -0.2, 0.1), (1.0, 0.1, -0.05), 1.5)
+    for n_sph in (0, 40):
+        box = cf.closed_box(dt, n_sph)
+        for kern in _kernels(gpu):
+            for mb, seed, spp in ((10, 1, 1), (10, 77, 5), (3, 4, 3), (0, 9, 2)):
+                img = hip_render(gpu, box, 24, 16, cam=cam, kernel=kern, rays_per_pixel=spp, seed=seed, max_bounces=mb)
+                assert np.all(img == cf.closed_box_value(mb)), (n_sph, kern, mb)
+    for kern in _kernels(gpu):
+        assert not hip_render(gpu, cf.inside_a_sphere(dt), 24, 16, kernel=kern, rays_per_pixel=2).any(), kern
+        for direction, dist in cf.TRIANGLE_CASES:
+            for delta in (-1e-9, 1e-9):
+                objs, tcam, cfg, want = cf.triangle_distance_bracket(dt, direction, dist, delta)
+                img = hip_render(gpu, objs, 1, 1, cam=tcam, kernel=kern, **cfg)
+                assert tuple(img.ravel()) == tuple(want), (kern, direction, delta)
+
+
+def test_closed_box_at_two_stage_size_every_ray_survives(gpu):
+    """The same closed box with 300 spheres at 1024 x 1024 (1.05e6 rays: AUTO = the sphere kernel in two stages, stage 1 as
+    packets): EVERY primary ray survives its first hit, so the survivors' queue takes as many records as the launch has
+    rays -- the case its capacity and chunk reservation are sized for; a record it could not take raises the launch's
+    watchdog word (an error from render_rows / close) instead of vanishing.  Every pixel is 1.9990234375 exactly."""
+    import torch
+    import closed_form as cf
+    box = cf.closed_box(gpu.OBJECT_DTYPE, 300, seed=8)
+    w = h = 1024
+    for tune in (0, gpu.RTX_TUNE_NO_PACKETS):
+        hnd = hip_scene(gpu, box, cam=((0.3, -0.2, 0.1), (1.0, 0.1, -0.05), 1.5), rays_per_pixel=1, seed=3, tuning=tune).upload(0)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        assert st.kernel == gpu.RTX_KERNEL_BVH and st.segments == 11 * w * h and st.stage1_ms > 0
+        assert bool((buf == cf.closed_box_value(10)).all())
+        buf.zero_()
+        hnd.render_rows(w, h, 0, 1, h, buf.data_ptr(), want_stats=False)          # asynchronous: a raised watchdog word surfaces in close()
+        hnd.close()
+        assert bool((buf == cf.closed_box_value(10)).all())
+
+
 # ---- properties that hold at any size --------------------------------------------------------------------
 def test_emission_only_scene_is_seed_independent_and_exact(gpu, oracle):
     from rust_raytracing_amd import scenes
@@ -411,6 +456,36 @@ def test_mesh_kernel_paths(gpu, oracle):
     needles["geom"][:, 6:9] = needles["geom"][:, 0:3] + (needles["geom"][:, 3:6] - needles["geom"][:, 0:3]) * 0.5 + 1e-5   # area ~ 1e-5
     needles["geom"][::2, 2] = needles["geom"][::2, 5] = needles["geom"][::2, 8]                                             # every other one edge-on in z
     both(needles, scenes.CAMERA, w=96, h=54)
+
+
+def test_wavefront_overflow_list_saturates_cleanly(gpu):
+    """The wavefront form's per-level overflow list (65 536 entries) written far beyond its capacity: 14 coincident
+    triangles fill the view, so every primary ray of a 512x512x8 frame (2.1e6 rays: packets) holds more live candidates
+    than its 6-entry queue and flushes; the first ~8k flushes fill the list, the reservation that straddles the cap must
+    leave no unwritten or stale entry behind (they are marked as nobody's), every later ray takes the exhaustive fallback.
+    Twice on the same handle (the list is not cleared between launches), against the exhaustive f64 kernel bit for bit."""
+    import torch
+    from rust_raytracing_amd import scenes
+    mesh = scenes.light_every(scenes.compact(scenes.random_triangles(1500, 6), k=0.05, x0=5.0))
+    mesh["geom"][100:114] = (3.0, -9.0, -9.0, 3.3, 9.0, -9.0, 3.6, 0.0, 12.0)      # a stack of 14 that covers the 90-degree view
+    mesh["emission_color"][100:114] = np.linspace(0.1, 0.9, 14)[:, None]
+    mesh["base_color"][100:114] = 0.5
+    w, h, spp = 512, 512, 8
+    out = {}
+    for kern in (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_KERNEL_EXACT):
+        hnd = hip_scene(gpu, mesh, kernel=kern, rays_per_pixel=spp, seed=7).upload(0)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        for _ in range(2 if kern == gpu.RTX_KERNEL_WAVEFRONT else 1):
+            buf.zero_()
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            assert st.kernel == kern
+            out.setdefault(kern, []).append((buf.cpu().numpy(), st.segments, st.exact_tests))
+        hnd.close()
+    ref = out[gpu.RTX_KERNEL_EXACT][0]
+    for img, segs, exact in out[gpu.RTX_KERNEL_WAVEFRONT]:
+        assert np.array_equal(img, ref[0]) and segs == ref[1]
+    assert out[gpu.RTX_KERNEL_WAVEFRONT][0][2] > 100 * ref[1] // 4            # the fallback did run for most segments
+    assert ref[0].mean() > 0.01
 
 
 def test_auto_takes_the_wavefront_form_for_a_resident_mesh(gpu, oracle):
@@ -1128,7 +1203,13 @@ def _check_roofline(r):
         assert key in r, key
     assert r["bound"] == "valu" and abs(r["peak"] - 78.6432) < 1e-3 and r["unit"] == "Tlane-op/s"
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9        # a fraction of a real ceiling
-    assert 0.0 < r["algorithmic"]["frac_of_valu_peak"] <= 1.0
+    assert 0.0 < r["algorithmic"]["frac_of_valu_peak"] <= 1.0 and r["frac"] == r["algorithmic"]["frac_of_valu_peak"]   # frac = the USEFUL fraction
+    if r.get("issued"):                                   # the issued fraction on the same scale: never below the useful one
+        assert r["frac"] <= r["issued"]["frac"] <= 1.0
+        ident = r["valu_busy"] * r["lane_utilisation"] * 2.0 / r["valu_cycles_per_instruction"]
+        assert abs(ident - r["issued"]["frac"]) < 1e-9
+        for k in r.get("kernels", []):
+            assert k["avg_ms_per_launch"] > 0 and (k.get("issued_frac") is None or 0 < k["issued_frac"] <= 1.0)
     if r["traffic"] is not None:
         assert 0.0 < r["hbm_frac"] <= 1.0 and r["traffic"] >= r["traffic_raw"] > 0
         assert abs(r["hbm_gbs"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["hbm_gbs"]
@@ -1138,7 +1219,7 @@ def test_bench_line_contract(gpu):
     """bench.py at a reduced sample count (counters off: they are the next test): one JSON line with the contract's keys,
     strong scaling by default, roofline objects that are fractions of a real ceiling for the value kernel, the LDS sweep
     and the three other configs, a cpu_baseline on the benchmark's own view, and the two kernels' frames bit-identical."""
-    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C4=2,C5=1", "--no-pmc"])
+    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1", "--no-pmc"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs", "lds_sweep"):
         assert key in d, key
@@ -1148,18 +1229,28 @@ def test_bench_line_contract(gpu):
     _check_roofline(d["roofline"])
     assert d["roofline"]["traffic"] is None or "profiles/pmc_counters.json" in d["roofline"]["counters_source"]
     c = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample", "Msegments_s", "faithful_Mrays_s"):
+    for key in ("value", "unit", "cores", "kind", "sample", "Msegments_s", "faithful_Mrays_s", "single_thread_Mrays_s", "threads_started",
+                "parallel_efficiency"):
         assert key in c, key
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert c["kind"] == "port" and c["value"] > 0 and c["single_thread_Mrays_s"] > 0
+    # `cores` is the threads' worth the pool DELIVERED (pool rate / single-thread rate), not what the scheduler advertises
+    assert 0.5 <= c["cores"] <= c["threads_started"] * 1.5 and abs(c["cores"] - c["value"] / c["single_thread_Mrays_s"]) < 0.06
     # the CPU leg samples the GPU's own view: same segments per primary ray up to sampling noise
     assert abs(c["segments_per_primary_ray"] - d["segments_per_primary_ray"]) < 0.35
     assert d["speedup_vs_cpu"]["primary_rays"] > 100 and d["speedup_vs_cpu"]["segments"] > 100
     assert d["lds_sweep"]["image_identical_to_value_kernel"] is True
     _check_roofline(d["lds_sweep"]["roofline"])
-    assert [o["config"] for o in d["other_configs"]] == ["C3", "C4", "C5"]
+    assert d["speedup_vs_cpu"]["like_for_like_linear_scan"] > 10          # the LDS sweep scans the list as the CPU does
+    assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5"]
+    assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, True]
+    assert d["other_configs"][1]["band_rate_over_full_frame_rate"] > 0
     for o in d["other_configs"]:
         assert o["value"] > 0 and o["Msegments_per_s"] > 0 and 1.0 <= o["segments_per_primary_ray"] <= 11.0
         _check_roofline(o["roofline"])
+    # (at 2 spp the frame is 4.1e6 rays: the sphere kernel's two stages) stage 1 and stage 2 reported separately and adding up
+    st = d["roofline"]["stages"]
+    assert len(st) == 2 and abs(st[0]["ms"] + st[1]["ms"] - d["roofline"]["avg_launch_ms"]) < 1e-6
+    assert st[0]["segments"] == 1920 * 1080 * 2 and all(0 < s_["frac"] <= 1 for s_ in st)
 
 
 def test_bench_collects_counters_in_the_run(gpu):
@@ -1172,7 +1263,10 @@ def test_bench_collects_counters_in_the_run(gpu):
     r = d["roofline"]
     assert "of this run" in r["counters_source"], (r["counters_source"], d.get("log"))
     _check_roofline(r)
-    assert r["frac_source"].startswith("SQ_THREAD_CYCLES_VALU") and 0.0 < r["lane_utilisation"] <= 1.0
+    assert r["issued"]["source"].startswith("SQ_THREAD_CYCLES_VALU") and 0.0 < r["lane_utilisation"] <= 1.0
+    syms = [k["kernel"] for k in r["kernels"]]
+    assert "trace_sph_packet_kernel" in syms and any(k.endswith("<false, 2>") for k in syms)      # per kernel symbol of the launch
+    assert all("issued_frac" in s_ and "lane_utilisation" in s_ for s_ in r["stages"])
     assert r["traffic"] > 1920 * 1080 * 2 * 24            # at least the sample planes were written
     assert d["hbm_gbs"] == r["hbm_gbs"]
 

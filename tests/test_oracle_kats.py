@@ -244,6 +244,26 @@ def test_quantize_image(oracle):                              # scene.rs:175-178
 
 
 # ---- committed golden images --------------------------------------------------------------------
+# ---- values that follow from the reference's text alone (tests/closed_form.py): they pin the oracle here and, in
+#      test_gpu_parity.py, the device path -- each against the reference, not against one another
+def test_closed_form_values_pin_the_oracle(oracle, rtx):
+    import closed_form as cf
+    dt = rtx.OBJECT_DTYPE
+    cam = ((0.3, -0.2, 0.1), (1.0, 0.1, -0.05), 1.5)
+    for n_sph in (0, 40):
+        box = cf.closed_box(dt, n_sph)
+        for mb, seed, spp in ((10, 1, 1), (10, 77, 5), (3, 4, 3), (0, 9, 2)):
+            img = oracle_render(oracle, box, 24, 16, cam=cam, rays_per_pixel=spp, seed=seed, max_bounces=mb)
+            assert np.all(img == cf.closed_box_value(mb)), (n_sph, mb)
+    assert cf.closed_box_value(10) == 1.9990234375 and cf.closed_box_value(3) == 1.875
+    assert not oracle_render(oracle, cf.inside_a_sphere(dt), 24, 16, rays_per_pixel=2).any()
+    for direction, dist in cf.TRIANGLE_CASES:
+        for delta in (-1e-9, 1e-9):
+            objs, tcam, cfg, want = cf.triangle_distance_bracket(dt, direction, dist, delta)
+            img = oracle_render(oracle, objs, 1, 1, cam=tcam, **cfg)
+            assert tuple(img.ravel()) == tuple(want), (direction, delta)
+
+
 @pytest.mark.parametrize("name", ["c1_three_spheres_32x32", "spheres200_48x27", "mixed_40x24", "tris300_32x18"])
 def test_oracle_reproduces_golden(oracle, name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

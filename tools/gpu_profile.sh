@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the bench line (with its live rocprofv3 counter passes), then the rocprofv3 kernel-trace
 # summary of the same command.  Outputs under gpurun_out/$TAG/; tools/store_profiles.py copies the judged files to profiles/.
-#   tools/gpu_profile.sh r02
+#   tools/gpu_profile.sh r03
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,13 +14,18 @@ python - <<PY
 import json
 d = json.load(open("$OUT/bench_n1.json"))
 r = d["roofline"]
-print("value %.1f Mrays/s  %.2f ms/step  frac %.3f (%s)  lane_util %s  hbm_frac %s  cpu %.4f Mrays/s x%.0f" % (
-    d["value"], d["ms_per_step"], r["frac"], r["frac_source"], r["lane_utilisation"], r["hbm_frac"],
-    d["cpu_baseline"]["value"], d["speedup_vs_cpu"]["primary_rays"]))
+iss = (r.get("issued") or {}).get("frac")
+print("value %.1f Mrays/s  %.2f ms/step  useful frac %.3f  issued frac %s  lane_util %s  valu_busy %s  hbm_frac %s  cpu %.4f Mrays/s (%s threads' worth) x%.0f" % (
+    d["value"], d["ms_per_step"], r["frac"], iss, r["lane_utilisation"], r["valu_busy"], r["hbm_frac"],
+    d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["speedup_vs_cpu"]["primary_rays"]))
+for s_ in r.get("stages", []):
+    print("    %s: %.2f ms  useful %.3f issued %s lanes %s busy %s salu %s" % (s_["stage"], s_["ms"], s_["frac"], s_.get("issued_frac"), s_.get("lane_utilisation"), s_.get("valu_busy"), s_.get("salu_busy")))
 for o in d.get("other_configs", []):
-    print("  %s %.1f Mrays/s  %.1f Mseg/s  frac %.3f  hbm_frac %s" % (o["config"], o["value"], o["Msegments_per_s"], o["roofline"]["frac"], o["roofline"]["hbm_frac"]))
+    print("  %s %.1f Mrays/s  %.1f Mseg/s  useful %.3f issued %s hbm_frac %s %s" % (o["config"], o["value"], o["Msegments_per_s"], o["roofline"]["frac"], (o["roofline"].get("issued") or {}).get("frac"), o["roofline"]["hbm_frac"], "band/full %.3f" % o["band_rate_over_full_frame_rate"] if "band_rate_over_full_frame_rate" in o else ("band" if "band" in o["workload"] else "full")))
+    for k in o["roofline"].get("kernels", []):
+        print("      %-45s %.2f ms issued %s lanes %s busy %s" % (k["kernel"][:45], k["avg_ms_per_launch"], k.get("issued_frac"), k.get("lane_utilisation"), k.get("valu_busy")))
 if "lds_sweep" in d:
-    print("  lds_sweep %.1f Mrays/s frac %.3f" % (d["lds_sweep"]["value"], d["lds_sweep"]["roofline"]["frac"]))
+    print("  lds_sweep %.1f Mrays/s useful %.3f issued %s" % (d["lds_sweep"]["value"], d["lds_sweep"]["roofline"]["frac"], (d["lds_sweep"]["roofline"].get("issued") or {}).get("frac")))
 print("log:", d.get("log"))
 PY
 export TMPDIR=/tmp
@@ -30,3 +35,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 find $OUT/trace -name "*kernel_stats.csv" | head -3
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 head -8 "$f" | cut -c1-200
+
+for leg in "C3 8" "C5 4 band"; do
+  set -- $leg
+  echo "[gpu_profile] rocprofv3 --kernel-trace --stats of $leg"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$1 -- python3 $R/tools/ab_kernels.py $1 $2 0 $3 > $OUT/trace_$1.log 2>&1 || { tail -20 $OUT/trace_$1.log; exit 1; }
+  f=$(find $OUT/trace_$1 -name "*kernel_stats.csv" | head -1)
+  head -6 "$f" | cut -c1-160
+done

@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of one config under one kernel id: per-kernel totals (the wavefront form is ~23 kernels per launch).
-#   tools/kernel_breakdown.sh TAG CONFIG SPP KERNEL [band]      -> gpurun_out/r02/TAG/
+#   tools/kernel_breakdown.sh TAG CONFIG SPP KERNEL [band]      -> gpurun_out/${TAG:-r03}/TAG/
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/r02/$1
+OUT=$R/gpurun_out/${TAG:-r03}/$1
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
