@@ -122,6 +122,8 @@ enum {
     RTX_TUNE_THRESH_SHIFT   = 12,    /* bits 12..18: lanes that wait before the regrouping kernels' f64 phase runs, 1..64
                                         (0 = default) */
     RTX_TUNE_PK_LDS_STACK = 1u << 20, /* mesh packets: the wave-uniform stack in LDS (round 2) instead of in the lanes of a VGPR */
+    RTX_TUNE_STAGE2_POOL = 1u << 21, /* sphere trees, two stages: stage 2 as a wave-local pool of ray slots (trace_sph_pool_kernel;
+                                        an experiment, slower than the lock-step form that ships) */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };
@@ -284,7 +286,7 @@ int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out
  * invariants: every child box inside its parent's, every sphere / triangle-footprint inside its leaf's box, every
  * shape of the tree in exactly one leaf, links and layout flags consistent, depth as recorded.  stats[16]:
  * 0 spheres, 1 triangles, 2 triangle filter records, 3 of them in the tree, 4 wide nodes, 5 depth, 6 binary nodes,
- * 7 flags (1 spheres in the tree, 2 triangles in the tree, 4 nothing but (x, y)-footprint triangles: every node is a footprint node, 8 the 64-byte node form exists), 8 sphere leaf entries seen, 9 triangle leaf entries seen,
+ * 7 flags (1 spheres in the tree, 2 triangles in the tree, 4 nothing but (x, y)-footprint triangles: every node is a footprint node, 8 the 64-byte footprint-node form exists, 16 the 64-byte form of a sphere tree exists), 8 sphere leaf entries seen, 9 triangle leaf entries seen,
  * 10 largest leaf, 11 flat (footprint) nodes, 12 stack entries bound (3*depth+2), 13 tree triangles whose footprint lies in
  * the (x, y) plane, 14 those with an (x, z) or (y, z) footprint (zero-pivot row swaps, triangle.rs:60-71,81-87), 15 nodes that also exist in the 64-byte quantised form (flag 8). */
 int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats);

@@ -90,6 +90,7 @@ struct RtxSceneHandle_ {
     double *h_tables = nullptr; size_t h_tables_doubles = 0;
     double *state = nullptr;    size_t state_bytes = 0;
     void *wf_state = nullptr;   size_t wf_bytes = 0;       // the wavefront kernels' ray state
+    void *pool = nullptr;       size_t pool_bytes = 0;     // the sphere kernel's stage-2 slots
     Counters *counters = nullptr;
     unsigned long long *work_counter = nullptr;
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
@@ -173,6 +174,7 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->h_tables) (void)hipHostFree(h->h_tables);
     if (h->state) (void)hipFree(h->state);
     if (h->wf_state) (void)hipFree(h->wf_state);
+    if (h->pool) (void)hipFree(h->pool);
     if (h->counters) (void)hipFree(h->counters);
     if (h->counters_stage1) (void)hipFree(h->counters_stage1);
     if (h->work_counter) (void)hipFree(h->work_counter);
@@ -202,6 +204,7 @@ struct PackedScene {
     BvhBuild bvh;
     Bvh4Build bvh4;
     std::vector<BvhQNode> qnodes;                    // the 64-byte form of bvh4's nodes, when the tree allows it
+    std::vector<BvhQ3Node> q3nodes;                  // the 64-byte form of a sphere tree's nodes
 };
 
 int32_t pack_scene(const RtxScene *scene, PackedScene &p)
@@ -389,6 +392,8 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
                      (bvh.has_tris && !bvh.has_spheres && tree_recs[1].empty() && tree_recs[0].empty() ? 4u : 0u);
     if ((p.sv.bvh_flags & 4u) && build_qnodes(bvh4, p.qnodes)) p.sv.bvh_flags |= 8u;
     else p.qnodes.clear();
+    if ((p.sv.bvh_flags & 3u) == 1u && build_q3nodes(bvh4, bvh.abs_pad, p.q3nodes)) p.sv.bvh_flags |= 16u;     // spheres only
+    else p.q3nodes.clear();
     if (debug_prints())
         std::fprintf(stderr, "[rtx_hip] upload: %zu spheres, %zu triangles (%zu in the tree: %zu xy / %zu xz / %zu yz footprints, %zu tested per segment), bvh: %zu binary nodes, %zu wide nodes, depth %d\n",
                      spheres.size(), tris.size(), n_in_tree, tree_recs[2].size(), tree_recs[1].size(), tree_recs[0].size(),
@@ -433,6 +438,7 @@ int32_t upload_packed(RtxSceneHandle_ *h, const PackedScene &p)
     int32_t rc = RTX_OK;
     if (!rc) rc = upload_vec(h, p.bvh4.nodes, &h->sv.bvh_nodes);
     if (!rc) rc = upload_vec(h, p.qnodes, &h->sv.bvh_qnodes);
+    if (!rc) rc = upload_vec(h, p.q3nodes, &h->sv.bvh_q3nodes);
     if (!rc) rc = upload_vec(h, p.bvh.prims, &h->sv.bvh_prims);
     if (!rc) rc = upload_vec(h, p.leaf32, &h->sv.bvh_leaf_f32);
     if (!rc) rc = upload_vec(h, p.leaf_cr, &h->sv.bvh_leaf_cr);
@@ -820,6 +826,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                    (batch * per_sample64 >= (1ull << 20) || (tuning & RTX_TUNE_TWO_STAGE) != 0u);
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
+        if (tuning & RTX_TUNE_STAGE2_POOL)
+            if (int32_t rc = grow(&h->pool, &h->pool_bytes, bvh_spheres_pool2_bytes(h->n_cus))) return rc;
     }
     if (kernel == RTX_KERNEL_WAVEFRONT) {
         const size_t need = wf_mesh ? wavefront_spill_bytes(h->sv, h->n_cus) : wavefront_spheres_spill_bytes(h->sv, h->n_cus);
@@ -886,9 +894,10 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                 RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus,
                                                        spheres_two_stage ? h->wf_state : nullptr,
-                                                       ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u), stream,
+                                                       ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u) |
+                                                           ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u), stream,
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
-                                                       stats && spheres_two_stage ? h->ev[3] : nullptr));
+                                                       stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & RTX_TUNE_STAGE2_POOL) ? h->pool : nullptr));
             else
                 RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
@@ -1258,6 +1267,31 @@ int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
             }
         }
         stats[15] = p.qnodes.size();
+    }
+    if (p.sv.bvh_flags & 16u) {                    // a sphere tree's 64-byte form: every decoded child box contains the 128-byte node's
+        if (p.q3nodes.size() != n_nodes) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: 64-byte sphere node count differs");
+        for (size_t k = 0; k < n_nodes; ++k) {
+            const Bvh4Node &w = p.bvh4.nodes[k];
+            const BvhQ3Node &q = p.q3nodes[k];
+            const uint32_t *lows[3] = { &q.lox, &q.loy, &q.loz }, *highs[3] = { &q.hix, &q.hiy, &q.hiz };
+            const float org[3] = { q.ox, q.oy, q.oz }, stp[3] = { q.sx, q.sy, q.sz };
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t count = bits(w.b[c].w), type = q.link[c] >> kQNodeShift;
+                if ((count == 0xFFFFFFFFu) != (type == kQNodeEmpty)) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: 64-byte sphere node: empty slot differs");
+                if (type == kQNodeEmpty) continue;
+                if ((q.link[c] & kQNodeIndexMask) != bits(w.a[c].w) || (type == 0u) != (count == 0u) || (type != 0u && type != count))
+                    return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: 64-byte sphere node: link / count differs");
+                const float l[3] = { w.a[c].x, w.a[c].y, w.a[c].z }, hh[3] = { w.b[c].x, w.b[c].y, w.b[c].z };
+                for (int a = 0; a < 3; ++a) {
+                    // decoded exactly as the device does: one f32 FMA of an exact product
+                    const float dl = std::fmaf((float)((*lows[a] >> (8 * c)) & 255u), stp[a], org[a]);
+                    const float dh = std::fmaf((float)((*highs[a] >> (8 * c)) & 255u), stp[a], org[a]);
+                    if (!((double)dl <= (double)l[a] - p.bvh.abs_pad * 0.999 && (double)dh >= (double)hh[a] + p.bvh.abs_pad * 0.999))
+                        return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: decoded 64-byte box does not contain the child's (+ pad)");
+                }
+            }
+        }
+        stats[15] = p.q3nodes.size();
     }
     if (depth != p.bvh4.depth) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: recorded depth differs");
     for (size_t k = 0; k < n_nodes; ++k) if (!node_seen[k]) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: unreachable node");

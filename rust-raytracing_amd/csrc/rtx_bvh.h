@@ -507,4 +507,79 @@ inline bool build_qnodes(const Bvh4Build &b4, std::vector<BvhQNode> &out)
     return true;
 }
 
+
+// ---- 64-byte nodes of a sphere tree -----------------------------------------------------------------------------------------
+// A per-lane walk fetches its node as address-divergent 16-byte requests, and the L1's request rate (about one per cycle per
+// CU) is what bounds the bounced rays of a sphere scene before the VALUs do (2.5e10 requests per C2 launch).
+// A 128-byte node costs 8 requests; this form costs 4: the child boxes as 8-bit offsets on the node's own grid,
+//     {ox, oy, oz, sx}   {sy, sz, lo.x[4], lo.y[4]}   {lo.z[4], hi.x[4], hi.y[4], hi.z[4]}   {link[4]}
+// (byte c of a packed word = child c).  plane = o + q * s with s a power of two and o a multiple of s, so the decoded plane
+// is exact in f32 (checked at build: |o / s| + 255 < 2^24); lo is rounded down and hi up AFTER another abs_pad was added, so
+// the decoded box contains the 128-byte node's box with the margin the extra roundings of the decode need.
+// link = type << 29 | index, type 0 interior, 1..6 sphere leaf with that many entries, 7 empty (as BvhQNode).
+struct BvhQ3Node {
+    float ox, oy, oz, sx;
+    float sy, sz;
+    uint32_t lox, loy;
+    uint32_t loz, hix, hiy, hiz;
+    uint32_t link[4];
+};
+static_assert(sizeof(BvhQ3Node) == 64, "BvhQ3Node must be 64 bytes");
+
+inline bool build_q3nodes(const Bvh4Build &b4, double abs_pad, std::vector<BvhQ3Node> &out)
+{
+    out.clear();
+    out.reserve(b4.nodes.size());
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    for (const Bvh4Node &w : b4.nodes) {
+        double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        uint32_t cnt[4], lnk[4];
+        for (int c = 0; c < 4; ++c) {
+            cnt[c] = bits(w.b[c].w); lnk[c] = bits(w.a[c].w);
+            if (cnt[c] == 0xFFFFFFFFu) continue;
+            const float l[3] = { w.a[c].x, w.a[c].y, w.a[c].z }, h[3] = { w.b[c].x, w.b[c].y, w.b[c].z };
+            for (int a = 0; a < 3; ++a) {
+                if (!std::isfinite(l[a]) || !std::isfinite(h[a])) return false;      // a footprint (unbounded) child: no 64-byte form
+                lo[a] = std::min(lo[a], (double)l[a] - abs_pad); hi[a] = std::max(hi[a], (double)h[a] + abs_pad);
+            }
+        }
+        BvhQ3Node q;
+        std::memset(&q, 0, sizeof q);
+        double o[3], sc[3];
+        for (int a = 0; a < 3; ++a) {
+            const double ext = std::isfinite(lo[a]) ? hi[a] - lo[a] : 0.0;
+            sc[a] = ext > 0.0 ? std::exp2(std::ceil(std::log2(ext / 254.0))) : 1.0;
+            if (!(sc[a] >= 1.1754944e-38 && sc[a] <= 1.0e30)) return false;
+            o[a] = std::isfinite(lo[a]) ? std::floor(lo[a] / sc[a]) * sc[a] : 0.0;      // a multiple of the step
+            while (std::isfinite(lo[a]) && (hi[a] - o[a]) / sc[a] > 255.0) { sc[a] *= 2.0; o[a] = std::floor(lo[a] / sc[a]) * sc[a]; }
+            if (!(std::fabs(o[a] / sc[a]) + 256.0 < 16777216.0)) return false;          // o + q * s must be exact in f32
+            if ((double)(float)o[a] != o[a]) return false;
+        }
+        q.ox = (float)o[0]; q.oy = (float)o[1]; q.oz = (float)o[2]; q.sx = (float)sc[0]; q.sy = (float)sc[1]; q.sz = (float)sc[2];
+        uint32_t *lows[3] = { &q.lox, &q.loy, &q.loz }, *highs[3] = { &q.hix, &q.hiy, &q.hiz };
+        for (int c = 0; c < 4; ++c) {
+            if (cnt[c] == 0xFFFFFFFFu) {                          // empty: an inverted box (lo 255, hi 0) is never entered
+                for (int a = 0; a < 3; ++a) *lows[a] |= 255u << (8 * c);
+                q.link[c] = kQNodeEmpty << kQNodeShift;
+                continue;
+            }
+            const float l[3] = { w.a[c].x, w.a[c].y, w.a[c].z }, h[3] = { w.b[c].x, w.b[c].y, w.b[c].z };
+            for (int a = 0; a < 3; ++a) {
+                const double ql = std::floor(((double)l[a] - abs_pad - o[a]) / sc[a]), qh = std::ceil(((double)h[a] + abs_pad - o[a]) / sc[a]);
+                if (ql < 0 || qh > 255 || ql > qh) return false;
+                *lows[a] |= (uint32_t)ql << (8 * c);
+                *highs[a] |= (uint32_t)qh << (8 * c);
+            }
+            uint32_t type;
+            if (cnt[c] == 0u) type = 0u;
+            else if ((cnt[c] & kBvhTriLeaf) == 0u && cnt[c] >= 1u && cnt[c] <= kQNodeLeafMax) type = cnt[c];
+            else return false;                                    // a triangle leaf or a bigger leaf: no 64-byte form
+            if (lnk[c] > kQNodeIndexMask || (lnk[c] & kBvhFlatNode)) return false;
+            q.link[c] = (type << kQNodeShift) | lnk[c];
+        }
+        out.push_back(q);
+    }
+    return true;
+}
+
 }  // namespace rtx

@@ -91,7 +91,7 @@ __device__ __forceinline__ void sph_queue_close(const SphQueue &sq, uint32_t lan
         if (s < sq.capacity) sq.rec[s].ridx = kNone;
 }
 
-template <bool SPILL, int MODE>
+template <bool SPILL, int MODE, bool Q3 = false>          // Q3: `nodes` are the 64-byte nodes (rtx_bvh.h BvhQ3Node), 4 float4 each
 __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spheres_kernel(const SceneView *__restrict__ svp,
                                                                              const RowsView *__restrict__ rvp,
                                                                              double *__restrict__ samples, Counters *__restrict__ ctr,
@@ -197,7 +197,16 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                 SphereRay sr;
                 sphere_ray_from(sv, r.pos, r.dir, sr);
                 const V3 dirn = rx.dirn;
-                if (in32) {
+                if constexpr (Q3) {                   // (a far origin walks the same tree with Ray32S's slack instead of an f64 slab test)
+                    Ray32 q0;
+                    make_ray32(r.pos, dirn, (double)sv.bvh_inv_max, q0);
+                    Ray32S q;
+                    q.ix = q0.ix; q.iy = q0.iy; q.iz = q0.iz; q.nx = q0.nx; q.ny = q0.ny; q.nz = q0.nz;
+                    q.e = ray32_slack(q0.nx, q0.ny, q0.nz, in32);
+                    bvh_traverse_spheres_q3<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, sv.bvh_root, &lds_stack[0][0],
+                                                          lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
+                                                          overflow, nbox, nleaf);
+                } else if (in32) {
                     Ray32 q;
                     make_ray32(r.pos, dirn, (double)sv.bvh_inv_max, q);
                     bvh_traverse_spheres<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, sv.bvh_root, &lds_stack[0][0],
@@ -306,6 +315,7 @@ constexpr int kSpkStack = 63;                // wave-uniform stack entries: the 
 #endif
 constexpr int kSpkWaves = RTX_SPK_WAVES;     // workgroups per CU
 constexpr uint32_t kSphNoPackets = 1u;       // launch flag: stage 1 per lane (A/B runs)
+constexpr uint32_t kSphPool = 4u;            // launch flag: stage 2 as the wave-local pool (an experiment: slower) instead of lock-step
 constexpr uint32_t kSphSortSurvivors = 2u;   // launch flag: stage 2 reads the survivors ordered by exit distance and octant
 
 // The walk of one tile.  SGN < 8: every ray of the tile points into octant SGN (bit a set: direction component a is
@@ -601,6 +611,307 @@ __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kerne
     }
 }
 
+// ---- stage 2 as a wave-local pool -----------------------------------------------------------------------------------------
+// Stage 2's lock-step form (MODE 2 above) issues 2.6 lane-slots per lane-instruction it needs: every round of a wave lasts
+// as long as the longest of its 64 walks (21 node visits on average, ~55 for the slowest lane: lane utilisation 0.39,
+// profiles/r03_bench_n1.json).  Refilling a lane the moment its walk ends needs a segment that is READY to walk, and making one
+// ready is the f64 phase (exact tests, ray_hit, set-up: ~1300 wave-instructions whether 1 or 64 lanes take part) -- which is
+// why the schedules that served waiting lanes in small groups lost.  Here the two are decoupled INSIDE the wave:
+//   * a wave owns kPoolSlots = 128 ray slots in device memory (f64 path state, the walk's f32 parameters, the candidates);
+//     a slot is READY (set up, waiting for a lane), WALKING (a lane owns it), DONE (its walk ended, candidates stored) or dead;
+//   * every iteration idle lanes take READY slots (ballot + mbcnt over a wave-local list in LDS: no atomics) and all walking
+//     lanes do one sphere_step -- the walk runs with (almost) all lanes;
+//   * when 64 slots are DONE (or the lanes starve) the whole wave runs ONE f64 phase over 64 DONE slots -- lane i serves slot
+//     done[i], not the ray it is walking --: exact tests, ray_hit, then the next segment's set-up (-> READY), or the sample
+//     store and a fresh survivor from stage 1's queue into the same slot.  The f64 phase runs with all lanes.
+// Same functions in the same order per ray: same bits.  No barrier, no atomic besides the queue chunk grab; every
+// iteration either walks, or consumes DONE slots, or ends the wave.
+constexpr int kPoolSlots = 128;
+constexpr int kPoolStack = kSphStack - 1;         // LDS stack entries per lane (one row less than MODE 2: the row pays for the lists)
+constexpr uint32_t kPoolFresh = 1u << 10, kPoolNoWalk = 1u << 9, kPoolOverflow = 1u << 8;
+#ifndef RTX_POOL_SERVE
+#define RTX_POOL_SERVE 24
+#endif
+#ifndef RTX_POOL_WAIT
+#define RTX_POOL_WAIT 8
+#endif
+constexpr uint32_t kPoolWait = RTX_POOL_WAIT;      // lanes whose walk has ended wait until this many have, then they are served together
+constexpr uint32_t kPoolServe = RTX_POOL_SERVE;    // idle lanes (with nothing READY) that trigger an f64 phase before 64 slots are DONE
+constexpr int kPoolF64 = 13, kPoolU32 = 28;       // fields per slot
+struct SphPool {
+    double *f;              // field k of slot i: f[k * stride + i]   (0-2 pos, 3-5 dir, 6-8 result, 9-11 light, 12 rng key)
+    uint32_t *u;            // 0 ridx, 1 bounce, 2 qcnt | flags, 3-6 candidate index, 7-10 candidate t_lo, 11 best_up,
+    size_t stride;          // 12-17 Ray32 ix iy iz nx ny nz, 18 slack, 19-27 SphereRay px py pz dx dy dz Kg c0 K
+};
+
+size_t bvh_spheres_pool2_bytes(int n_cus)
+{
+    const size_t slots = (size_t)n_cus * kSphWavesPerSimd * (kBvhThreads / 64) * kPoolSlots;
+    return slots * (kPoolF64 * sizeof(double) + kPoolU32 * sizeof(uint32_t)) + 512;
+}
+
+template <bool SPILL>
+__global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_pool_kernel(const SceneView *__restrict__ svp,
+                                                                              const RowsView *__restrict__ rvp,
+                                                                              double *__restrict__ samples, Counters *__restrict__ ctr,
+                                                                              unsigned long long *__restrict__ work_counter,
+                                                                              const float4 *__restrict__ nodes, const LeafArrays la,
+                                                                              uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                                              const SphQueue sq, const SphPool pool)
+{
+    constexpr int STACK = kPoolStack;
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    __shared__ uint32_t lds_stack[STACK + 1][kBvhThreads];
+    __shared__ uint32_t lds_q[2 * kSphQueue][kBvhThreads];
+    __shared__ uint8_t lds_lists[kBvhThreads >> 6][2][kPoolSlots];     // per wave: [0] DONE slots, [1] READY slots
+    uint32_t *const lq = &lds_q[0][0];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint8_t *const done_list = &lds_lists[tid >> 6][0][0], *const ready_list = &lds_lists[tid >> 6][1][0];
+    const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
+    const size_t base = ((size_t)blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) * kPoolSlots;     // this wave's slots
+    const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
+    const unsigned long long n_rays = *sq.count < sq.capacity ? *sq.count : sq.capacity;
+    // (volatile: a slot is written by one lane and read by another of the same wave later on; the accesses must reach the
+    //  memory system as written, in order, and not be kept in registers or a stale line)
+    volatile double *const pf = pool.f;
+    volatile uint32_t *const pu = pool.u;
+    const size_t ps = pool.stride;
+
+    unsigned long long wave_next = 0, wave_end = 0;
+    bool queue_empty = false;
+    uint32_t n_done = kPoolSlots, n_ready = 0;                         // wave-uniform
+    for (uint32_t s = lane; s < (uint32_t)kPoolSlots; s += 64u) {      // every slot starts DONE + FRESH: the first f64 phases fill the pool
+        done_list[s] = (uint8_t)s;
+        pu[2 * ps + base + s] = kPoolFresh;
+    }
+    bool walking = false;
+    uint32_t slot = 0, node = kNone, sp = 0, qcnt = 0, nbox = 0, nleaf = 0;
+    bool overflow = false;
+    float best_up = 0.f;
+    Ray32S q;
+    SphereRay sr;
+    q.ix = q.iy = q.iz = 1.f; q.nx = q.ny = q.nz = q.e = 0.f;
+    sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
+    unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
+
+    for (;;) {
+        // ---- idle lanes take READY slots (the list's tail)
+        unsigned long long idle_mask = __ballot(!walking);
+        uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (n_idle != 0u && n_ready != 0u) {
+            const uint32_t k = bvh_mbcnt(idle_mask);
+            if (!walking && k < n_ready) {
+                slot = ready_list[n_ready - 1u - k];
+                const size_t i = base + slot;
+                q.ix = __uint_as_float(pu[12 * ps + i]); q.iy = __uint_as_float(pu[13 * ps + i]); q.iz = __uint_as_float(pu[14 * ps + i]);
+                q.nx = __uint_as_float(pu[15 * ps + i]); q.ny = __uint_as_float(pu[16 * ps + i]); q.nz = __uint_as_float(pu[17 * ps + i]);
+                q.e = __uint_as_float(pu[18 * ps + i]);
+                sr.px = __uint_as_float(pu[19 * ps + i]); sr.py = __uint_as_float(pu[20 * ps + i]); sr.pz = __uint_as_float(pu[21 * ps + i]);
+                sr.dx = __uint_as_float(pu[22 * ps + i]); sr.dy = __uint_as_float(pu[23 * ps + i]); sr.dz = __uint_as_float(pu[24 * ps + i]);
+                sr.Kg = __uint_as_float(pu[25 * ps + i]); sr.c0 = __uint_as_float(pu[26 * ps + i]); sr.K = __uint_as_float(pu[27 * ps + i]);
+                node = sv.bvh_root; sp = 0; qcnt = 0; overflow = false; best_up = __builtin_inff();
+                walking = true;
+            }
+            n_ready -= n_idle < n_ready ? n_idle : n_ready;
+            idle_mask = __ballot(!walking);
+            n_idle = (uint32_t)__popcll(idle_mask);
+        }
+        // ---- the f64 phase, for up to 64 DONE slots, when it runs full -- or the walk is starving
+        if (n_done >= 64u || (n_done != 0u && n_ready == 0u && (n_idle == 64u || n_idle >= kPoolServe))) {
+            const uint32_t take = n_done < 64u ? n_done : 64u;
+            const bool have = lane < take;
+            const uint32_t my = have ? (uint32_t)done_list[n_done - 1u - lane] : 0u;
+            n_done -= take;
+            const size_t i = base + my;
+            uint32_t fl = have ? pu[2 * ps + i] : 0u;
+            RayState r;
+            uint32_t ridx = 0;
+            bool go = false;                                            // this slot has a segment to set up
+            // (a) a slot whose walk ended: closest_object's exact part + ray_hit
+            if (have && (fl & kPoolFresh) == 0u) {
+                r.pos = mk(pf[0 * ps + i], pf[1 * ps + i], pf[2 * ps + i]);
+                r.dir = mk(pf[3 * ps + i], pf[4 * ps + i], pf[5 * ps + i]);
+                r.result = mk(pf[6 * ps + i], pf[7 * ps + i], pf[8 * ps + i]);
+                r.light = mk(pf[9 * ps + i], pf[10 * ps + i], pf[11 * ps + i]);
+                r.key = (uint64_t)__double_as_longlong(pf[12 * ps + i]);
+                ridx = pu[0 * ps + i];
+                r.bounce = pu[1 * ps + i];
+                r.draw = 6u + 2u * r.bounce;
+                const float bu = __uint_as_float(pu[11 * ps + i]);
+                const RayX rx = make_rayx(r.pos, r.dir);
+                Hit h;
+                hit_init(h);
+                ++segs;
+                if ((fl & (kPoolOverflow | kPoolNoWalk)) == 0u) {
+                    const uint32_t nq = fl & 0xFFu;
+#pragma unroll 1
+                    for (uint32_t e = 0; e < nq; ++e) {
+                        if (__uint_as_float(pu[(7 + e) * ps + i]) <= bu) {
+                            const uint32_t idx = pu[(3 + e) * ps + i];
+                            double t;
+                            if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
+                            exact += 1;
+                        }
+                    }
+                } else {                                  // no walk (origin out of range / NaN) or a dropped candidate: every sphere
+                    for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+                        double t;
+                        if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
+                    }
+                    exact += sv.n_spheres;
+                }
+                for (uint32_t k = 0; k < sv.n_planes; ++k) {
+                    double t;
+                    if (plane_distance(sv.planes[k], rx, &t)) hit_consider(h, t, sv.planes[k].id, 1, k);
+                }
+                for (uint32_t k = 0; k < sv.n_tri_filter; ++k) {       // the few triangles of a sphere scene (none of them in the tree)
+                    const uint32_t tk = la.tri_fidx[k];
+                    double t;
+                    if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                }
+                exact += sv.n_planes + sv.n_tri_filter;
+                bool done = true;
+                if (h.id != kNone) {
+                    advance_and_shade(sv, h, r);
+                    done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
+                }
+                if (done) {
+                    store_sample(samples, rv, ridx, r.result);
+                    fl = kPoolFresh;                                    // the slot is free for the next survivor
+                } else go = true;
+            }
+            // (b) a free slot: the next survivor of stage 1's queue, as it is after its first hit
+            const unsigned long long fm = __ballot(have && (fl & kPoolFresh) != 0u);
+            bool dead = false;
+            if (fm != 0ull) {
+                if (wave_next >= wave_end && !queue_empty) {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(work_counter, (unsigned long long)rv.grab);
+                    b = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        __builtin_amdgcn_readfirstlane((uint32_t)b);
+                    wave_next = b;
+                    wave_end = b + rv.grab < n_rays ? b + rv.grab : n_rays;
+                    if (b >= n_rays) { queue_empty = true; wave_next = wave_end = 0; }
+                }
+                if (have && (fl & kPoolFresh) != 0u) {
+                    const unsigned long long rec = wave_next + bvh_mbcnt(fm);
+                    if (rec < wave_end) {
+                        const double4 *p = reinterpret_cast<const double4 *>(sq.rec + (sq.perm ? (unsigned long long)sq.perm[rec] : rec));
+                        const double4 s0 = p[0], s1 = p[1];
+                        ridx = (uint32_t)(unsigned long long)__double_as_longlong(s1.z);
+                        if (ridx != kNone) {
+                            uint32_t pl = 0, smp = 0;
+                            if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
+                            else ray_index_to_pixel(rv, ridx, pl, smp);
+                            const uint32_t k = pl / rv.width, x = pl - k * rv.width;
+                            const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
+                            r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
+                            r.bounce = 1u;
+                            r.draw = 8u;
+                            r.pos = mk(s0.x, s0.y, s0.z);
+                            r.dir = mk(s0.w, s1.x, s1.y);
+                            // ray_hit's two folds of the first hit (scene.rs:276-277) from resulting_color = 0, light_color = 1 (ray.rs:18-19)
+                            const MaterialX m = sv.materials[(uint32_t)((unsigned long long)__double_as_longlong(s1.z) >> 32)];
+                            r.result = vadd(mk(0.0, 0.0, 0.0), vmulv(mk(1.0, 1.0, 1.0), m.emission_color));
+                            r.light = vmulv(mk(1.0, 1.0, 1.0), m.base_color);
+                            go = true;
+                        }                                                // (a slot its wave reserved and did not use: asked again next time)
+                    } else if (queue_empty) dead = true;                 // nothing left to take: the slot retires
+                }
+                const unsigned long long taken = (unsigned long long)__popcll(fm);
+                wave_next = wave_next + taken < wave_end ? wave_next + taken : wave_end;
+            }
+            // (c) the segment's set-up: the walk's f32 parameters; the path state goes back to the slot
+            bool nowalk = false;
+            if (go) {
+                const RayX rn = make_rayx(r.pos, r.dir);
+                const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
+                                         __builtin_fabsf((float)r.pos.z));
+                const bool in32 = omax <= sv.bvh_origin_limit;                              // NaN origin -> no walk
+                if (in32 || omax <= sv.bvh_origin_limit * kBvhRange64) {
+                    SphereRay s2;
+                    sphere_ray_from(sv, r.pos, r.dir, s2);
+                    Ray32 q0;
+                    make_ray32(r.pos, rn.dirn, (double)sv.bvh_inv_max, q0);
+                    pu[12 * ps + i] = __float_as_uint(q0.ix); pu[13 * ps + i] = __float_as_uint(q0.iy); pu[14 * ps + i] = __float_as_uint(q0.iz);
+                    pu[15 * ps + i] = __float_as_uint(q0.nx); pu[16 * ps + i] = __float_as_uint(q0.ny); pu[17 * ps + i] = __float_as_uint(q0.nz);
+                    pu[18 * ps + i] = __float_as_uint(ray32_slack(q0.nx, q0.ny, q0.nz, in32));
+                    pu[19 * ps + i] = __float_as_uint(s2.px); pu[20 * ps + i] = __float_as_uint(s2.py); pu[21 * ps + i] = __float_as_uint(s2.pz);
+                    pu[22 * ps + i] = __float_as_uint(s2.dx); pu[23 * ps + i] = __float_as_uint(s2.dy); pu[24 * ps + i] = __float_as_uint(s2.dz);
+                    pu[25 * ps + i] = __float_as_uint(s2.Kg); pu[26 * ps + i] = __float_as_uint(s2.c0); pu[27 * ps + i] = __float_as_uint(s2.K);
+                } else nowalk = true;
+                pf[0 * ps + i] = r.pos.x; pf[1 * ps + i] = r.pos.y; pf[2 * ps + i] = r.pos.z;
+                pf[3 * ps + i] = r.dir.x; pf[4 * ps + i] = r.dir.y; pf[5 * ps + i] = r.dir.z;
+                pf[6 * ps + i] = r.result.x; pf[7 * ps + i] = r.result.y; pf[8 * ps + i] = r.result.z;
+                pf[9 * ps + i] = r.light.x; pf[10 * ps + i] = r.light.y; pf[11 * ps + i] = r.light.z;
+                pf[12 * ps + i] = __longlong_as_double((long long)r.key);
+                pu[0 * ps + i] = ridx;
+                pu[1 * ps + i] = r.bounce;
+                if (nowalk) { pu[2 * ps + i] = kPoolNoWalk; pu[11 * ps + i] = __float_as_uint(__builtin_inff()); }
+            } else if (have && !dead) {
+                pu[2 * ps + i] = kPoolFresh;                            // a free slot that got no survivor this time
+            }
+            // READY: set up and walkable.  DONE again: no walk possible (tested exhaustively next phase), or still free.
+            const bool to_ready = go && !nowalk, to_done = have && !dead && !to_ready;
+            const unsigned long long rm = __ballot(to_ready), dm = __ballot(to_done);
+            if (to_ready) ready_list[n_ready + bvh_mbcnt(rm)] = (uint8_t)my;
+            if (to_done) done_list[n_done + bvh_mbcnt(dm)] = (uint8_t)my;
+            n_ready += (uint32_t)__popcll(rm);
+            n_done += (uint32_t)__popcll(dm);
+            // free slots while the queue still has chunks are asked again; when it is empty they retired above, so a phase that
+            // only re-queued free slots cannot repeat for ever
+            continue;
+        }
+        if (n_idle == 64u) break;                  // nothing walking, nothing READY, nothing DONE: every slot retired
+        // ---- the walk: visits for every lane that has a node to open, until kPoolWait lanes have finished their walk (they
+        //      are then served together, so that the serve code does not run for two or three lanes on every visit), a READY
+        //      slot could be handed to an idle lane (nothing to hand out while the list is empty), or nobody walks any more.
+        //      A tight loop of its own: what the f64 phase spills stays outside it.
+        for (;;) {
+            if (walking && node != kNone)
+                sphere_step<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, node, sp, &lds_stack[0][0], lq, tid, spill, spill_entries,
+                                          spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+            const uint32_t n_fin = (uint32_t)__popcll(__ballot(walking && node == kNone));
+            if (n_fin >= kPoolWait || __ballot(walking && node != kNone) == 0ull) break;
+        }
+        const bool fin = walking && node == kNone;
+        const unsigned long long fmask = __ballot(fin);
+        if (fin) {                                                       // the candidates that can still be the winner go to the slot
+            const size_t i = base + slot;
+#pragma unroll
+            for (int e = 0; e < kSphQueue; ++e) {
+                if ((uint32_t)e < qcnt) {
+                    pu[(3 + e) * ps + i] = lq[(size_t)e * kBvhThreads + tid];
+                    pu[(7 + e) * ps + i] = lq[(size_t)(kSphQueue + e) * kBvhThreads + tid];
+                }
+            }
+            pu[11 * ps + i] = __float_as_uint(best_up);
+            pu[2 * ps + i] = qcnt | (overflow ? kPoolOverflow : 0u);
+            done_list[n_done + bvh_mbcnt(fmask)] = (uint8_t)slot;
+            box_tests += nbox; leaf_filters += nleaf;
+            nbox = 0; nleaf = 0;
+            walking = false;
+        }
+        n_done += (uint32_t)__popcll(fmask);
+    }
+    unsigned long long filt = box_tests + leaf_filters;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        segs += __shfl_xor(segs, off, 64);
+        exact += __shfl_xor(exact, off, 64);
+        filt += __shfl_xor(filt, off, 64);
+        box_tests += __shfl_xor(box_tests, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
+        if (segs) atomicAdd(&ctr[shard].segments, segs);
+        if (exact) atomicAdd(&ctr[shard].exact_tests, exact);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);
+    }
+}
+
 // ---- ordering the survivors for stage 2 ----------------------------------------------------------------------------------
 // A wave's round lasts as long as its longest walk, and how long a walk is depends mostly on how far the ray travels inside
 // the cloud.  The survivors are therefore binned by the distance at which their ray leaves the scene's box (kSortT bins) and
@@ -704,9 +1015,15 @@ uint32_t bvh_spheres_spill_entries(const SceneView &sv)
     return need > (uint32_t)kSphStack ? need - (uint32_t)kSphStack : 0u;
 }
 
+static uint32_t bvh_spheres_pool_spill_entries(const SceneView &sv)
+{
+    const uint32_t need = 3u * sv.bvh_depth + 2u;
+    return need > (uint32_t)kPoolStack ? need - (uint32_t)kPoolStack : 0u;
+}
+
 size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus)
 {
-    return (size_t)bvh_spheres_spill_entries(sv) * (size_t)n_cus * kSphWavesPerSimd * kBvhThreads * sizeof(uint32_t);
+    return (size_t)bvh_spheres_pool_spill_entries(sv) * (size_t)n_cus * kSphWavesPerSimd * kBvhThreads * sizeof(uint32_t);   // (the pool kernel's stack is the shorter one)
 }
 
 // the survivors' queue of the two-stage form: one 64-byte record per slot; capacity = the launch's rays (every ray can
@@ -731,7 +1048,8 @@ static bool sph_packets_ok(const SceneView &sv, const RowsView &rv)
 
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
-                                    void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot, hipEvent_t stage1_done)
+                                    void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot, hipEvent_t stage1_done,
+                                    void *pool_mem)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -792,6 +1110,26 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
         hipLaunchKernelGGL(sph_sort_scatter_kernel, dim3(sblocks), dim3(256), 0, stream, sq, so);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         sq.perm = so.perm;
+    }
+    if (pool_mem && (flags & kSphPool) != 0u) {
+        // stage 2 as a wave-local pool (trace_sph_pool_kernel): the grid is the resident waves, each with its own slots
+        SphPool pool{};
+        const size_t slots = (size_t)n_cus * kSphWavesPerSimd * (kBvhThreads / 64) * kPoolSlots;
+        pool.stride = slots;
+        pool.f = reinterpret_cast<double *>(pool_mem);
+        pool.u = reinterpret_cast<uint32_t *>(pool.f + (size_t)kPoolF64 * slots);
+        const uint32_t pool_spill = kPoolStack < (int)(3u * sv.bvh_depth + 2u) && spill ? 3u * sv.bvh_depth + 2u - (uint32_t)kPoolStack : 0u;
+        auto kp = pool_spill ? trace_sph_pool_kernel<true> : trace_sph_pool_kernel<false>;
+        hipLaunchKernelGGL(kp, dim3((uint32_t)cap), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, nodes, la, spill,
+                           pool_spill, sq, pool);
+        return hipGetLastError();
+    }
+    const bool q3 = (sv.bvh_flags & 16u) != 0u && sv.bvh_q3nodes != nullptr && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
+    if (q3) {       // the queue-fed stage walks per lane over the 64-byte nodes: half the L1 requests per visit
+        auto k2 = deep ? trace_bvh_spheres_kernel<true, 2, true> : trace_bvh_spheres_kernel<false, 2, true>;
+        hipLaunchKernelGGL(k2, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1,
+                           reinterpret_cast<const float4 *>(sv.bvh_q3nodes), la, spill, spill_entries, sq);
+        return hipGetLastError();
     }
     auto k2 = deep ? trace_bvh_spheres_kernel<true, 2> : trace_bvh_spheres_kernel<false, 2>;
     hipLaunchKernelGGL(k2, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, nodes, la, spill,

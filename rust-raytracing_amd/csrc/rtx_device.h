@@ -43,6 +43,7 @@ struct SceneView {
     // flat BVH over the sphere boxes and triangle footprints (rtx_bvh.h); null when the scene has none
     const Bvh4Node *bvh_nodes;                 // 4-wide nodes, 128 B each; node 0 is the root
     const BvhQNode *bvh_qnodes;                // the same nodes in the 64-byte quantised form (bvh_flags bit 3), else null
+    const BvhQ3Node *bvh_q3nodes;              // a sphere tree's nodes in their 64-byte form (bvh_flags bit 4), else null
     const uint32_t *bvh_prims;                 // local sphere indices, leaf-contiguous
     const float4   *bvh_leaf_f32;              // per sphere leaf entry: the sphere's filter record {c - centre, |c - centre|^2 - r^2}
     const float4   *bvh_leaf_cr;               // the same entries as {c - centre, |r|} (rounded up): the spheres kernel's record

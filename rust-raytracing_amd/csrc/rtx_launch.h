@@ -41,7 +41,9 @@ size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot = nullptr,
-                                    hipEvent_t stage1_done = nullptr);
+                                    hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr);
+// pool_mem: bvh_spheres_pool2_bytes(n_cus) bytes: stage 2 runs as a wave-local pool of ray slots (flags bit 2: the lock-step form)
+size_t bvh_spheres_pool2_bytes(int n_cus);
 // (stage1_snapshot: kCounterShards Counters that receive a copy of `counters` as stage 1 left them; stage1_done: recorded
 // after stage 1 -- both only for the two-stage form, both optional: what RtxStats' stage1_* fields are made of)
 

@@ -465,6 +465,129 @@ __device__ __forceinline__ void sphere_step(const float4 *__restrict__ nodes, co
     }
 }
 
+// The same visit over the 64-byte nodes (rtx_bvh.h BvhQ3Node): 4 address-divergent requests instead of 8 -- the per-lane walk
+// is bound by the L1's request rate before it is by the VALUs.  plane = o + q * s is exact (s a power of two, o a multiple of
+// s), so the slab distance is t = fl(q * S + O) with S = s * inv (exact: a power of two times inv) and O = fl(o * inv + noi):
+// against box_entry32's fl(b * inv + noi) that is ONE more rounding, of O, at most 2^-24 |o * inv + noi| -- in position terms
+// 2^-24 (|o| + |ray origin|), which the second abs_pad the 64-byte boxes were built with covers (rtx_bvh.h build_q3nodes) and,
+// for the part that scales with a far origin, Ray32S's slack.  Everything after the four entry distances is sphere_step's.
+template <int STACK, bool SPILL, class RAY>
+__device__ __forceinline__ void sphere_step_q3(const float4 *__restrict__ qnodes, const float4 *__restrict__ leaf_f32,
+                                               const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
+                                               uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                               uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                               size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
+                                               uint32_t &nbox, uint32_t &nleaf)
+{
+    const float4 *np = qnodes + 4 * (size_t)node;
+    const float4 h0 = np[0], h1 = np[1], h2 = np[2], h3 = np[3];
+    const float Sx = h0.w * q.ix, Sy = h1.x * q.iy, Sz = h1.y * q.iz;
+    const float Ox = __builtin_fmaf(h0.x, q.ix, q.nx), Oy = __builtin_fmaf(h0.y, q.iy, q.ny), Oz = __builtin_fmaf(h0.z, q.iz, q.nz);
+    const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);
+    const uint32_t hix = __float_as_uint(h2.y), hiy = __float_as_uint(h2.z), hiz = __float_as_uint(h2.w);
+    const uint32_t lk[4] = { __float_as_uint(h3.x), __float_as_uint(h3.y), __float_as_uint(h3.z), __float_as_uint(h3.w) };
+    const float e = ray_slack(q);
+    float tc[4];
+    uint32_t lnk[4], typ[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float x0 = __builtin_fmaf((float)((lox >> (8 * c)) & 255u), Sx, Ox), x1 = __builtin_fmaf((float)((hix >> (8 * c)) & 255u), Sx, Ox);
+        const float y0 = __builtin_fmaf((float)((loy >> (8 * c)) & 255u), Sy, Oy), y1 = __builtin_fmaf((float)((hiy >> (8 * c)) & 255u), Sy, Oy);
+        const float z0 = __builtin_fmaf((float)((loz >> (8 * c)) & 255u), Sz, Oz), z1 = __builtin_fmaf((float)((hiz >> (8 * c)) & 255u), Sz, Oz);
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);
+        const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);
+        typ[c] = lk[c] >> 29;
+        lnk[c] = lk[c] & 0x1FFFFFFFu;
+        tc[c] = (tn_lo <= tf_hi && tn_lo <= best_up && typ[c] != 7u) ? tn_lo : __builtin_inff();
+    }
+    nbox += 4;
+    uint32_t leafmask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (tc[c] < __builtin_inff() && typ[c] != 0u) leafmask |= 1u << c;                        // a sphere leaf the ray enters
+    while (leafmask != 0u) {
+        const uint32_t c = (uint32_t)__builtin_ctz(leafmask);
+        leafmask &= leafmask - 1u;
+        const uint32_t first = c == 0 ? lnk[0] : (c == 1 ? lnk[1] : (c == 2 ? lnk[2] : lnk[3]));
+        const uint32_t n = c == 0 ? typ[0] : (c == 1 ? typ[1] : (c == 2 ? typ[2] : typ[3]));
+        for (uint32_t k = 0; k < n; ++k) {
+            const float4 rec = leaf_f32[first + k];                              // {c - centre, r}
+            const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+            const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+            const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
+            const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+            const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+            const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+            const float Dp = Dl + G;
+            if (Dp >= 0.0f) {                                                     // the exact test cannot be excluded (sphere_step)
+                const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+                const float Dm = Dl - G;
+                const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+                if (tlo <= best_up && !(thi < 0.0f)) {
+                    if (tlo > sr.K) best_up = fminf(best_up, thi);
+                    if (qcnt == (uint32_t)kSphQueue) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int e2 = 0; e2 < kSphQueue; ++e2) {
+                            const uint32_t ie = lds_q[(size_t)e2 * kBvhThreads + tid];
+                            const uint32_t te = lds_q[(size_t)(kSphQueue + e2) * kBvhThreads + tid];
+                            if (__uint_as_float(te) <= best_up) {
+                                lds_q[(size_t)w * kBvhThreads + tid] = ie;
+                                lds_q[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                                w += 1;
+                            }
+                        }
+                        qcnt = w;
+                    }
+                    if (qcnt == (uint32_t)kSphQueue) overflow = true;
+                    else {
+                        lds_q[(size_t)qcnt * kBvhThreads + tid] = leaf_prims[first + k];
+                        lds_q[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                        qcnt += 1;
+                    }
+                }
+            }
+        }
+        nleaf += n;
+    }
+    float key[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) key[c] = (typ[c] == 0u && tc[c] <= best_up) ? tc[c] : __builtin_inff();
+#define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                           (key[3] < __builtin_inff() ? 1u : 0u);
+    if (sp + 3u <= (uint32_t)STACK) {
+#pragma unroll
+        for (uint32_t i = 1; i <= 3; ++i) {
+            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;
+            lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
+        }
+        sp += npush;
+    } else {
+#define RTX_PUSH(v)                                                                                  \
+        {                                                                                            \
+            if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
+            else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                \
+                spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;         \
+            } else overflow = true;                                                                  \
+        }
+        if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+        if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+        if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
+    }
+    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;
+        node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+    }
+}
+
 template <int STACK, bool SPILL, class RAY>
 __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ nodes, const float4 *__restrict__ leaf_f32,
                                                      const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
@@ -478,6 +601,21 @@ __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ 
     while (node != kNone)
         sphere_step<STACK, SPILL>(nodes, leaf_f32, leaf_prims, q, sr, node, sp, lds_stack, lds_q, tid, spill, spill_entries,
                                   spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+}
+
+template <int STACK, bool SPILL, class RAY>
+__device__ __forceinline__ void bvh_traverse_spheres_q3(const float4 *__restrict__ qnodes, const float4 *__restrict__ leaf_f32,
+                                                        const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
+                                                        uint32_t root, uint32_t *lds_stack, uint32_t *lds_q,
+                                                        uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                        size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
+                                                        uint32_t &nbox, uint32_t &nleaf)
+{
+    uint32_t sp = 0;
+    uint32_t node = root;
+    while (node != kNone)
+        sphere_step_q3<STACK, SPILL>(qnodes, leaf_f32, leaf_prims, q, sr, node, sp, lds_stack, lds_q, tid, spill, spill_entries,
+                                     spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
 }
 
 // A whole traversal of one lane's segment: steps until the stack is empty, the queued candidates' exact f64 tests

@@ -276,7 +276,7 @@ def test_bvh_invariants_on_the_benchmark_scenes(rtx):
     sphere / footprint inside its leaf's box, every shape in exactly one leaf, links, layout flags and depth consistent."""
     from rust_raytracing_amd import scenes
     st = _host_scene(rtx, scenes.random_spheres(10000, 1))                       # C2
-    assert st["flags"] == 1 and st["sphere_leaf_entries"] == 10000 and st["largest_leaf"] == 1 and st["flat_nodes"] == 0
+    assert st["flags"] == 1 + 16 and st["quantised_nodes"] == st["wide_nodes"] and st["sphere_leaf_entries"] == 10000 and st["largest_leaf"] == 1 and st["flat_nodes"] == 0
     assert st["depth"] <= 9 and st["stack_bound"] <= 30                          # C2 runs the LDS-stack-only kernel variant
     st = _host_scene(rtx, scenes.random_triangles(100000, 2))                    # C3
     assert st["flags"] == 2 + 4 + 8 and st["quantised_nodes"] == st["wide_nodes"] and st["tri_in_tree"] == st["tri_leaf_entries"] == st["tri_filter_records"]

@@ -340,7 +340,7 @@ def test_spheres_kernel_paths(gpu, oracle):
 
     deep = scenes.random_spheres(300000, 11)
     st = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*scenes.CAMERA), deep))
-    assert st["flags"] == 1 and st["stack_bound"] > 30                      # 3 * depth + 2 exceeds the LDS stack
+    assert st["flags"] == 1 + 16 and st["stack_bound"] > 30                      # 3 * depth + 2 exceeds the LDS stack
     img, segs, exact = both(deep, scenes.CAMERA)
     assert img.mean() > 0.01 and exact < 8 * segs, (exact, segs)              # (no exhaustive fallback: about one exact test per segment)
     c2 = scenes.random_spheres(10000, 1)

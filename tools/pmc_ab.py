@@ -13,7 +13,7 @@ for gi, ctrs in enumerate(groups):
     d = os.path.join(out, "g%d" % gi)
     cmd = ["rocprofv3", "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                           os.path.join(ROOT, "tools", "ab_kernels.py")] + rest
-    p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
     print("pass %d (%s): rc %d" % (gi, " ".join(ctrs), p.returncode), flush=True)
     if p.returncode != 0:
         print((p.stderr or p.stdout)[-600:])
