@@ -236,6 +236,19 @@ def sq_figures(c, t):
     return out
 
 
+def _sphere_stage_of(symbol):
+    """1 / 2 for the kernels of the sphere tree's two stages (trace_sph_packet_kernel | trace_bvh_spheres_kernel<SPILL, MODE[, Q3]>
+    | trace_sph_pool_kernel<...>), else 0."""
+    if symbol.startswith("trace_sph_packet_kernel"):
+        return 1
+    if symbol.startswith("trace_sph_pool_kernel"):
+        return 2
+    if symbol.startswith("trace_bvh_spheres_kernel<"):
+        args = [a.strip() for a in symbol[symbol.index("<") + 1:symbol.rindex(">")].split(",")]
+        return int(args[1]) if len(args) > 1 and args[1] in ("1", "2") else 0
+    return 0
+
+
 def roofline_of(acc, cfg, counters, source, per_kernel=None):
     """The roofline object of one measured kernel; `counters` = {counter: value per launch} or None; per_kernel = the same per
     kernel symbol ({symbol: {counter: per launch, "_ms": average duration, "_calls": rows per launch}})."""
@@ -297,9 +310,9 @@ def roofline_of(acc, cfg, counters, source, per_kernel=None):
         seg2 = acc.segments / steps / launches_per_step - seg1
         stages = []
         for name, ms, seg, box, filt, exact, sym in (
-                ("stage 1: primary rays", s1_ms, seg1, acc.s1_box, acc.s1_filter - acc.s1_box, acc.s1_exact, ("trace_sph_packet_kernel", "trace_bvh_spheres_kernel<false, 1>", "trace_bvh_spheres_kernel<true, 1>")),
+                ("stage 1: primary rays", s1_ms, seg1, acc.s1_box, acc.s1_filter - acc.s1_box, acc.s1_exact, 1),
                 ("stage 2: the rays that survived their first hit", s2_ms, seg2, acc.box - acc.s1_box,
-                 (acc.filter - acc.box) - (acc.s1_filter - acc.s1_box), acc.exact - acc.s1_exact, ("trace_bvh_spheres_kernel<false, 2>", "trace_bvh_spheres_kernel<true, 2>"))):
+                 (acc.filter - acc.box) - (acc.s1_filter - acc.s1_box), acc.exact - acc.s1_exact, 2)):
             box, filt, exact = box / max(acc.launches, 1), filt / max(acc.launches, 1), exact / max(acc.launches, 1)
             ops, _ = useful_ops(4, tri, box, filt, exact)
             rec = {"stage": name, "ms": ms, "segments": seg, "Msegments_per_s": seg / (ms * 1e-3) / 1e6 if ms > 0 else None,
@@ -308,7 +321,7 @@ def roofline_of(acc, cfg, counters, source, per_kernel=None):
                    "useful_Tlane_ops_per_s": ops / (ms * 1e-3) / 1e12 if ms > 0 else None,
                    "frac": ops / (ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS if ms > 0 else None}
             for k in out.get("kernels", []):
-                if any(k["kernel"].endswith(x) or x in k["kernel"] for x in sym):
+                if _sphere_stage_of(k["kernel"]) == sym:
                     rec.update({"kernel": k["kernel"], "issued_frac": k.get("issued_frac"), "lane_utilisation": k.get("lane_utilisation"),
                                 "valu_busy": k.get("valu_busy"), "salu_busy": k.get("salu_busy"), "ms_under_profiler": k.get("avg_ms_per_launch"),
                                 "traffic": k.get("traffic"), "fetch_bytes_corrected": k.get("fetch_bytes_corrected"), "write_bytes": k.get("write_bytes")})

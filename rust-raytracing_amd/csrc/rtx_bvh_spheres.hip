@@ -650,7 +650,7 @@ size_t bvh_spheres_pool2_bytes(int n_cus)
     return slots * (kPoolF64 * sizeof(double) + kPoolU32 * sizeof(uint32_t)) + 512;
 }
 
-template <bool SPILL>
+template <bool SPILL, bool Q3>
 __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_pool_kernel(const SceneView *__restrict__ svp,
                                                                               const RowsView *__restrict__ rvp,
                                                                               double *__restrict__ samples, Counters *__restrict__ ctr,
@@ -869,9 +869,14 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_pool_
         //      slot could be handed to an idle lane (nothing to hand out while the list is empty), or nobody walks any more.
         //      A tight loop of its own: what the f64 phase spills stays outside it.
         for (;;) {
-            if (walking && node != kNone)
-                sphere_step<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, node, sp, &lds_stack[0][0], lq, tid, spill, spill_entries,
-                                          spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+            if (walking && node != kNone) {
+                if constexpr (Q3)
+                    sphere_step_q3<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, node, sp, &lds_stack[0][0], lq, tid, spill,
+                                                 spill_entries, spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+                else
+                    sphere_step<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, node, sp, &lds_stack[0][0], lq, tid, spill,
+                                              spill_entries, spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+            }
             const uint32_t n_fin = (uint32_t)__popcll(__ballot(walking && node == kNone));
             if (n_fin >= kPoolWait || __ballot(walking && node != kNone) == 0ull) break;
         }
@@ -1119,9 +1124,11 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
         pool.f = reinterpret_cast<double *>(pool_mem);
         pool.u = reinterpret_cast<uint32_t *>(pool.f + (size_t)kPoolF64 * slots);
         const uint32_t pool_spill = kPoolStack < (int)(3u * sv.bvh_depth + 2u) && spill ? 3u * sv.bvh_depth + 2u - (uint32_t)kPoolStack : 0u;
-        auto kp = pool_spill ? trace_sph_pool_kernel<true> : trace_sph_pool_kernel<false>;
-        hipLaunchKernelGGL(kp, dim3((uint32_t)cap), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, nodes, la, spill,
-                           pool_spill, sq, pool);
+        const bool pq3 = (sv.bvh_flags & 16u) != 0u && sv.bvh_q3nodes != nullptr && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
+        auto kp = pq3 ? (pool_spill ? trace_sph_pool_kernel<true, true> : trace_sph_pool_kernel<false, true>)
+                      : (pool_spill ? trace_sph_pool_kernel<true, false> : trace_sph_pool_kernel<false, false>);
+        hipLaunchKernelGGL(kp, dim3((uint32_t)cap), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1,
+                           pq3 ? reinterpret_cast<const float4 *>(sv.bvh_q3nodes) : nodes, la, spill, pool_spill, sq, pool);
         return hipGetLastError();
     }
     const bool q3 = (sv.bvh_flags & 16u) != 0u && sv.bvh_q3nodes != nullptr && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
