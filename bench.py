@@ -120,7 +120,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip C3 / C4 band / C5 band at N = 1")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect rocprofv3 counters in this run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of each cpu_baseline mode")
-    ap.add_argument("--other-spp", default="C3=8,C3band=64,C4=64,C5=4", help="rays per pixel of the other_configs legs")
+    ap.add_argument("--other-spp", default="C3=8,C3band=64,C4=64,C5=1,C5band=4", help="rays per pixel of the other_configs legs")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the gather goes through gloo on host "
                          "copies (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
@@ -646,6 +646,18 @@ def main():
                "roofline": roofline_of(acc2, cfg, c2, src2, pk2)}
         handle.set_config(rcfg)
     image_mean = float(full.mean()) if full is not None else float("nan")
+    balance = None
+    if single and not args.no_other_configs:
+        # load balance of the 8-way partition (blocks of 8 rows dealt out round-robin): segments of every band of THIS frame, 4 spp
+        handle.set_config(rcfg.with_rays_per_pixel(4))
+        segs = []
+        for rk in range(8):
+            part = tiles.Partition(H, rk, 8)
+            band = part.alloc_band(W, dev)
+            segs.append(int(part.render(handle, W, band, want_stats=True).segments))
+        balance = {"parts": 8, "block_rows": tiles.ROW_BLOCK, "rays_per_pixel": 4, "segments_per_band": segs,
+                   "max_over_mean": max(segs) * 8.0 / max(sum(segs), 1)}
+        handle.set_config(rcfg)
     handle.close()
     del full
 
@@ -654,7 +666,7 @@ def main():
         other_spp = dict(kv.split("=") for kv in args.other_spp.split(","))
         others = []
         full_rate = {}
-        for name, band in (("C3", False), ("C3", True), ("C4", True), ("C5", True)):
+        for name, band in (("C3", False), ("C3", True), ("C4", True), ("C5", False), ("C5", True)):
             oc = CONFIGS[name]
             s = int(other_spp.get(name + "band" if band and name + "band" in other_spp else name, 4))
             o_objs = objs if oc["scene"] == cfg["scene"] and oc["n"] == cfg["n"] and oc["seed"] == cfg["seed"] else make_objects(oc)
@@ -677,6 +689,8 @@ def main():
                 full_rate[name] = rec["value"]
             elif name in full_rate:
                 rec["band_rate_over_full_frame_rate"] = rec["value"] / full_rate[name]
+            elif name == "C4":                          # C4 is C2's scene: its band against the value frame (equal spp by default)
+                rec["band_rate_over_full_frame_rate"] = rec["value"] / (W * H * spp * args.steps / elapsed / 1e6) if s == spp else None
             others.append(rec)
             del img, o_objs
 
@@ -706,6 +720,8 @@ def main():
             "hbm_gbs": roof["hbm_gbs"],
             "roofline": roof,
         }
+        if balance is not None:
+            line["partition_balance"] = balance
         if per_rank_segments is not None:
             line["segments_per_rank_per_step"] = per_rank_segments
             line["load_imbalance_max_over_mean"] = max(per_rank_segments) * world / max(sum(per_rank_segments), 1)

@@ -316,6 +316,21 @@ public:
     {
         return render_rows(width, height, 0, 1, height, d_out_rgb, hip_stream);
     }
+    // what rank `part` of `n_parts` of a multi-GPU job renders: the blocks of `block_rows` rows part, part + n_parts, ...
+    // (8 keeps the tree kernels' 8x8 ray tiles whole) -> d_out_rgb[band_rows(...)][width][3], rows in increasing image order
+    static std::size_t band_rows(std::size_t height, std::size_t block_rows, std::size_t part, std::size_t n_parts)
+    {
+        return rtx_blocks_row_count((uint32_t)height, (uint32_t)block_rows, (uint32_t)part, (uint32_t)n_parts);
+    }
+    RtxStats render_blocks(std::size_t width, std::size_t height, std::size_t block_rows, std::size_t part, std::size_t n_parts,
+                           double *d_out_rgb, void *hip_stream = nullptr)
+    {
+        RtxStats st{};
+        check(rtx_render_blocks(h_, (uint32_t)width, (uint32_t)height, (uint32_t)block_rows, (uint32_t)part, (uint32_t)n_parts,
+                                d_out_rgb, hip_stream, &st));
+        return st;
+    }
+    void set_scratch_limit(std::uint64_t bytes) { check(rtx_scene_set_scratch_limit(h_, bytes)); }
 
 private:
     friend class Scene;

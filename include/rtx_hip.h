@@ -124,6 +124,7 @@ enum {
     RTX_TUNE_PK_LDS_STACK = 1u << 20, /* mesh packets: the wave-uniform stack in LDS (round 2) instead of in the lanes of a VGPR */
     RTX_TUNE_STAGE2_POOL = 1u << 21, /* sphere trees, two stages: stage 2 as a wave-local pool of ray slots (trace_sph_pool_kernel;
                                         an experiment, slower than the lock-step form that ships) */
+    RTX_TUNE_STAGE2_PAIR = 1u << 22, /* sphere trees, two stages: stage 2 with two rays per lane (trace_sph_pair_kernel) */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };

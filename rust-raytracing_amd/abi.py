@@ -21,6 +21,7 @@ RTX_TUNE_TRI_LEAF_SHIFT, RTX_TUNE_THRESH_SHIFT = 8, 12
 RTX_TUNE_SORT_SURVIVORS = 1 << 19
 RTX_TUNE_PK_LDS_STACK = 1 << 20
 RTX_TUNE_STAGE2_POOL = 1 << 21
+RTX_TUNE_STAGE2_PAIR = 1 << 22
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)

@@ -826,8 +826,10 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                    (batch * per_sample64 >= (1ull << 20) || (tuning & RTX_TUNE_TWO_STAGE) != 0u);
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
-        if (tuning & RTX_TUNE_STAGE2_POOL)
-            if (int32_t rc = grow(&h->pool, &h->pool_bytes, bvh_spheres_pool2_bytes(h->n_cus))) return rc;
+        if (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) {
+            const size_t a = bvh_spheres_pool2_bytes(h->n_cus), b = bvh_spheres_pair_bytes(h->n_cus);
+            if (int32_t rc = grow(&h->pool, &h->pool_bytes, a > b ? a : b)) return rc;
+        }
     }
     if (kernel == RTX_KERNEL_WAVEFRONT) {
         const size_t need = wf_mesh ? wavefront_spill_bytes(h->sv, h->n_cus) : wavefront_spheres_spill_bytes(h->sv, h->n_cus);
@@ -895,9 +897,9 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus,
                                                        spheres_two_stage ? h->wf_state : nullptr,
                                                        ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u) |
-                                                           ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u), stream,
+                                                           ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u) | ((tuning & RTX_TUNE_STAGE2_PAIR) ? 8u : 0u), stream,
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
-                                                       stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & RTX_TUNE_STAGE2_POOL) ? h->pool : nullptr));
+                                                       stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr));
             else
                 RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));

@@ -315,6 +315,7 @@ constexpr int kSpkStack = 63;                // wave-uniform stack entries: the 
 #endif
 constexpr int kSpkWaves = RTX_SPK_WAVES;     // workgroups per CU
 constexpr uint32_t kSphNoPackets = 1u;       // launch flag: stage 1 per lane (A/B runs)
+constexpr uint32_t kSphPair = 8u;            // launch flag: stage 2 with two rays per lane (trace_sph_pair_kernel)
 constexpr uint32_t kSphPool = 4u;            // launch flag: stage 2 as the wave-local pool (an experiment: slower) instead of lock-step
 constexpr uint32_t kSphSortSurvivors = 2u;   // launch flag: stage 2 reads the survivors ordered by exit distance and octant
 
@@ -917,6 +918,317 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_pool_
     }
 }
 
+// ---- stage 2 with two rays per lane ----------------------------------------------------------------------------------------
+// The pool above pays a round trip to memory whenever a lane changes rays.  This form keeps the hand-over in REGISTERS: every
+// lane owns two rays.  While it walks one, the other is either DONE (its walk ended: candidates in 10 registers, waiting for
+// the f64 phase) or in the lane's POCKET (set up: the walk's 16 f32 parameters in registers, ready to go).  A lane whose walk
+// ends takes its pocket ray on the spot -- no memory access, no waiting -- and the wave runs ONE f64 phase for all lanes that
+// hold a DONE ray once kPairServe of them do (or nobody can walk): exact tests, ray_hit, the next segment's set-up into the
+// pocket (or the sample store and a fresh survivor from stage 1's queue).  Only the f64 path state of the two rays lives in
+// memory, lane-private and coalesced (slot s of lane l of wave w: field[(2 w + s) * 64 + l]), read and written once per segment
+// by the f64 phase.  Same functions in the same order per ray: same bits.
+#ifndef RTX_PAIR_SERVE
+#define RTX_PAIR_SERVE 56
+#endif
+constexpr uint32_t kPairServe = RTX_PAIR_SERVE;       // lanes holding a DONE ray (or idle lanes) that trigger the f64 phase
+#ifndef RTX_PAIR_WAIT
+#define RTX_PAIR_WAIT 8
+#endif
+constexpr uint32_t kPairWait = RTX_PAIR_WAIT;
+#ifndef RTX_PAIR_WAVES
+#define RTX_PAIR_WAVES 3
+#endif
+constexpr int kPairWaves = RTX_PAIR_WAVES;         // workgroups per CU
+constexpr int kPairF64 = 13;                      // pos, dir, result, light, rng key
+constexpr int kPairU32 = 2;                       // ridx, bounce
+
+size_t bvh_spheres_pair_bytes(int n_cus)
+{
+    const size_t lanes2 = (size_t)n_cus * kSphWavesPerSimd * kBvhThreads * 2;
+    return lanes2 * (kPairF64 * sizeof(double) + kPairU32 * sizeof(uint32_t)) + 512;
+}
+
+struct SphPair { double *f; uint32_t *u; size_t stride; };
+
+template <bool SPILL, bool Q3>
+__global__ __launch_bounds__(kBvhThreads, kPairWaves) void trace_sph_pair_kernel(const SceneView *__restrict__ svp,
+                                                                              const RowsView *__restrict__ rvp,
+                                                                              double *__restrict__ samples, Counters *__restrict__ ctr,
+                                                                              unsigned long long *__restrict__ work_counter,
+                                                                              const float4 *__restrict__ nodes, const LeafArrays la,
+                                                                              uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                                              const SphQueue sq, const SphPair pp)
+{
+    constexpr int STACK = kSphStack;
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    __shared__ uint32_t lds_stack[STACK + 1][kBvhThreads];
+    __shared__ uint32_t lds_q[2 * kSphQueue][kBvhThreads];
+    __shared__ uint32_t lds_dbuf[2 * kSphQueue + 2][kBvhThreads];        // a DONE ray's candidates, flags and bound (per lane)
+    uint32_t *const lq = &lds_q[0][0];
+    uint32_t *const ld = &lds_dbuf[0][0];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
+    const size_t wave = (size_t)blockIdx.x * (kBvhThreads >> 6) + (tid >> 6);
+    const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
+    const unsigned long long n_rays = *sq.count < sq.capacity ? *sq.count : sq.capacity;
+    double *const pf = pp.f;
+    uint32_t *const pu = pp.u;
+    const size_t ps = pp.stride;
+
+    unsigned long long wave_next = 0, wave_end = 0;
+    bool queue_empty = false;
+    // the ray being walked
+    bool walking = false;
+    uint32_t ws = 0, node = kNone, sp = 0, qcnt = 0, nbox = 0, nleaf = 0;
+    bool overflow = false;
+    float best_up = 0.f;
+    Ray32S q;
+    SphereRay sr;
+    q.ix = q.iy = q.iz = 1.f; q.nx = q.ny = q.nz = q.e = 0.f;
+    sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
+    // the pocket: the lane's other ray, set up (slot 1 - ws while the lane walks)
+    bool pocket = false, pocket_nowalk = false;
+    uint32_t pslot = 0;
+    Ray32S pq = q;
+    SphereRay psr = sr;
+    // DONE rays: a finished walk's candidates, flags and bound move to the lane's column of lds_dbuf (no memory access in the
+    // hand-over); when the lane's other ray is DONE already they stay where they are, in the walk's LDS queue, and the lane
+    // waits for the f64 phase
+    bool have_done = false, lds_done = false;
+    uint32_t dslot = 0, lslot = 0, lflags = 0;
+    float lbu = 0.f;
+    uint32_t free_slots = 3u;                         // bit s: slot s of this lane holds no ray
+    uint32_t segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;        // (per lane: far below 2^32)
+
+    // the hand-over, inside the walk loop and outside it: a lane whose walk has ended parks its candidates (registers, or --
+    // when its other ray is DONE already -- where they are, in its LDS queue), and a lane that does not walk takes its pocket
+#define RTX_PAIR_HANDOVER()                                                                                          \
+    {                                                                                                                \
+        if (walking && node == kNone) {                                                                              \
+            walking = false;                                                                                         \
+            box_tests += nbox; leaf_filters += nleaf;                                                                \
+            nbox = 0; nleaf = 0;                                                                                     \
+            const uint32_t fl_ = qcnt | (overflow ? kPoolOverflow : 0u);                                             \
+            if (!have_done) {                                                                                        \
+                _Pragma("unroll") for (int e = 0; e < 2 * kSphQueue; ++e)                                            \
+                    ld[(size_t)e * kBvhThreads + tid] = lq[(size_t)e * kBvhThreads + tid];                           \
+                ld[(size_t)(2 * kSphQueue) * kBvhThreads + tid] = fl_;                                               \
+                ld[(size_t)(2 * kSphQueue + 1) * kBvhThreads + tid] = __float_as_uint(best_up);                      \
+                dslot = ws;                                                                                          \
+                have_done = true;                                                                                    \
+            } else {                                                                                                 \
+                lslot = ws; lflags = fl_; lbu = best_up;                                                             \
+                lds_done = true;                                                                                     \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (!walking && pocket && !lds_done) {                                                                       \
+            pocket = false;                                                                                          \
+            ws = pslot;                                                                                              \
+            if (pocket_nowalk) { /* no f32 walk for this origin: DONE at once, every sphere gets the exact test */   \
+                if (!have_done) {                                                                                    \
+                    ld[(size_t)(2 * kSphQueue) * kBvhThreads + tid] = kPoolNoWalk;                                   \
+                    ld[(size_t)(2 * kSphQueue + 1) * kBvhThreads + tid] = __float_as_uint(__builtin_inff());         \
+                    dslot = ws; have_done = true;                                                                    \
+                } else { lds_done = true; lslot = ws; lflags = kPoolNoWalk; lbu = __builtin_inff(); }                \
+            } else {                                                                                                 \
+                q = pq; sr = psr;                                                                                    \
+                node = sv.bvh_root; sp = 0; qcnt = 0; overflow = false; best_up = __builtin_inff();                  \
+                walking = true;                                                                                      \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+
+    for (;;) {
+        RTX_PAIR_HANDOVER()
+        uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+        uint32_t n_done = (uint32_t)__popcll(__ballot(have_done));
+        const uint32_t n_fresh = (uint32_t)__popcll(__ballot(free_slots != 0u && !queue_empty));   // lanes that would take a survivor
+        if (n_walk == 0u && n_done == 0u && n_fresh == 0u) break;       // nobody walks, nothing DONE, nothing to fetch, no pocket left
+        // the f64 phase is due when kPairServe lanes hold a DONE ray, when that many lanes are idle and there is anything for
+        // it to do, or when nobody walks
+#define RTX_PAIR_DUE() (n_walk == 0u || n_done >= kPairServe || (64u - n_walk >= kPairServe && n_done + n_fresh != 0u))
+        // ---- the walk: visits, with the hand-over in the loop (every kPairWait finished walks), until the f64 phase is due.
+        //      What the f64 phase spills is moved once per phase, not once per hand-over.
+        if (!RTX_PAIR_DUE()) {
+            for (;;) {
+                if (walking && node != kNone) {
+                    if constexpr (Q3)
+                        sphere_step_q3<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, node, sp, &lds_stack[0][0], lq, tid, spill,
+                                                     spill_entries, spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+                    else
+                        sphere_step<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, node, sp, &lds_stack[0][0], lq, tid, spill,
+                                                  spill_entries, spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+                }
+                const uint32_t n_fin = (uint32_t)__popcll(__ballot(walking && node == kNone));
+                if (n_fin >= kPairWait || __ballot(walking && node != kNone) == 0ull) {
+                    RTX_PAIR_HANDOVER()
+                    n_walk = (uint32_t)__popcll(__ballot(walking));
+                    n_done = (uint32_t)__popcll(__ballot(have_done));
+                    if (RTX_PAIR_DUE()) break;
+                }
+            }
+        }
+#undef RTX_PAIR_DUE
+        // ---- the f64 phase: for the lanes that hold a DONE ray (or an empty slot while the queue has survivors)
+        {
+            RayState r;
+            uint32_t ridx = 0, slot = 0;
+            bool go = false;
+            if (have_done) {
+                slot = dslot;
+                have_done = false;
+                const size_t i = (wave * 2 + slot) * 64 + lane;
+                const uint32_t dflags = ld[(size_t)(2 * kSphQueue) * kBvhThreads + tid];
+                const float dbu = __uint_as_float(ld[(size_t)(2 * kSphQueue + 1) * kBvhThreads + tid]);
+                r.pos = mk(pf[0 * ps + i], pf[1 * ps + i], pf[2 * ps + i]);
+                r.dir = mk(pf[3 * ps + i], pf[4 * ps + i], pf[5 * ps + i]);
+                r.result = mk(pf[6 * ps + i], pf[7 * ps + i], pf[8 * ps + i]);
+                r.light = mk(pf[9 * ps + i], pf[10 * ps + i], pf[11 * ps + i]);
+                r.key = (uint64_t)__double_as_longlong(pf[12 * ps + i]);
+                ridx = pu[0 * ps + i];
+                r.bounce = pu[1 * ps + i];
+                r.draw = 6u + 2u * r.bounce;
+                const RayX rx = make_rayx(r.pos, r.dir);
+                Hit h;
+                hit_init(h);
+                ++segs;
+                if ((dflags & (kPoolOverflow | kPoolNoWalk)) == 0u) {
+                    const uint32_t nq = dflags & 0xFFu;
+#pragma unroll 1
+                    for (uint32_t e = 0; e < nq; ++e) {
+                        if (__uint_as_float(ld[(size_t)(kSphQueue + e) * kBvhThreads + tid]) <= dbu) {
+                            const uint32_t idx = ld[(size_t)e * kBvhThreads + tid];
+                            double t;
+                            if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
+                            exact += 1;
+                        }
+                    }
+                } else {                                  // no walk (origin out of range / NaN) or a dropped candidate: every sphere
+                    for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+                        double t;
+                        if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
+                    }
+                    exact += sv.n_spheres;
+                }
+                for (uint32_t k = 0; k < sv.n_planes; ++k) {
+                    double t;
+                    if (plane_distance(sv.planes[k], rx, &t)) hit_consider(h, t, sv.planes[k].id, 1, k);
+                }
+                for (uint32_t k = 0; k < sv.n_tri_filter; ++k) {
+                    const uint32_t tk = la.tri_fidx[k];
+                    double t;
+                    if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                }
+                exact += sv.n_planes + sv.n_tri_filter;
+                bool done = true;
+                if (h.id != kNone) {
+                    advance_and_shade(sv, h, r);
+                    done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
+                }
+                if (done) {
+                    store_sample(samples, rv, ridx, r.result);
+                    free_slots |= 1u << slot;
+                } else go = true;
+            }
+            // an empty slot takes the next survivor of stage 1's queue, as it is after its first hit
+            const bool ask = !go && free_slots != 0u && !queue_empty;
+            const unsigned long long fm = __ballot(ask);
+            if (fm != 0ull) {
+                if (wave_next >= wave_end && !queue_empty) {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(work_counter, (unsigned long long)rv.grab);
+                    b = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        __builtin_amdgcn_readfirstlane((uint32_t)b);
+                    wave_next = b;
+                    wave_end = b + rv.grab < n_rays ? b + rv.grab : n_rays;
+                    if (b >= n_rays) { queue_empty = true; wave_next = wave_end = 0; }
+                }
+                if (ask) {
+                    const unsigned long long rec = wave_next + bvh_mbcnt(fm);
+                    if (rec < wave_end) {
+                        const double4 *p = reinterpret_cast<const double4 *>(sq.rec + (sq.perm ? (unsigned long long)sq.perm[rec] : rec));
+                        const double4 s0 = p[0], s1 = p[1];
+                        ridx = (uint32_t)(unsigned long long)__double_as_longlong(s1.z);
+                        if (ridx != kNone) {
+                            slot = (free_slots & 1u) ? 0u : 1u;
+                            free_slots &= ~(1u << slot);
+                            uint32_t pl = 0, smp = 0;
+                            if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
+                            else ray_index_to_pixel(rv, ridx, pl, smp);
+                            const uint32_t k = pl / rv.width, x = pl - k * rv.width;
+                            const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
+                            r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
+                            r.bounce = 1u;
+                            r.draw = 8u;
+                            r.pos = mk(s0.x, s0.y, s0.z);
+                            r.dir = mk(s0.w, s1.x, s1.y);
+                            // ray_hit's two folds of the first hit (scene.rs:276-277) from resulting_color = 0, light_color = 1 (ray.rs:18-19)
+                            const MaterialX m = sv.materials[(uint32_t)((unsigned long long)__double_as_longlong(s1.z) >> 32)];
+                            r.result = vadd(mk(0.0, 0.0, 0.0), vmulv(mk(1.0, 1.0, 1.0), m.emission_color));
+                            r.light = vmulv(mk(1.0, 1.0, 1.0), m.base_color);
+                            go = true;
+                        }
+                    }
+                }
+                const unsigned long long taken = (unsigned long long)__popcll(fm);
+                wave_next = wave_next + taken < wave_end ? wave_next + taken : wave_end;
+            }
+            // the segment's set-up: path state back to the slot, the walk's parameters into the pocket -- or straight into the walk
+            if (go) {
+                const size_t i = (wave * 2 + slot) * 64 + lane;
+                pf[0 * ps + i] = r.pos.x; pf[1 * ps + i] = r.pos.y; pf[2 * ps + i] = r.pos.z;
+                pf[3 * ps + i] = r.dir.x; pf[4 * ps + i] = r.dir.y; pf[5 * ps + i] = r.dir.z;
+                pf[6 * ps + i] = r.result.x; pf[7 * ps + i] = r.result.y; pf[8 * ps + i] = r.result.z;
+                pf[9 * ps + i] = r.light.x; pf[10 * ps + i] = r.light.y; pf[11 * ps + i] = r.light.z;
+                pf[12 * ps + i] = __longlong_as_double((long long)r.key);
+                pu[0 * ps + i] = ridx;
+                pu[1 * ps + i] = r.bounce;
+                const RayX rn = make_rayx(r.pos, r.dir);
+                const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
+                                         __builtin_fabsf((float)r.pos.z));
+                const bool in32 = omax <= sv.bvh_origin_limit;                              // NaN origin -> no walk
+                pocket_nowalk = !(in32 || omax <= sv.bvh_origin_limit * kBvhRange64);
+                if (!pocket_nowalk) {
+                    sphere_ray_from(sv, r.pos, r.dir, psr);
+                    Ray32 q0;
+                    make_ray32(r.pos, rn.dirn, (double)sv.bvh_inv_max, q0);
+                    pq.ix = q0.ix; pq.iy = q0.iy; pq.iz = q0.iz; pq.nx = q0.nx; pq.ny = q0.ny; pq.nz = q0.nz;
+                    pq.e = ray32_slack(q0.nx, q0.ny, q0.nz, in32);
+                }
+                pocket = true;
+                pslot = slot;
+            }
+            // a second DONE ray that waited in the walk's LDS queue becomes the lane's DONE ray (and frees the queue)
+            if (lds_done) {
+#pragma unroll
+                for (int e = 0; e < 2 * kSphQueue; ++e) ld[(size_t)e * kBvhThreads + tid] = lq[(size_t)e * kBvhThreads + tid];
+                ld[(size_t)(2 * kSphQueue) * kBvhThreads + tid] = lflags;
+                ld[(size_t)(2 * kSphQueue + 1) * kBvhThreads + tid] = __float_as_uint(lbu);
+                dslot = lslot;
+                have_done = true;
+                lds_done = false;
+            }
+        }
+    }
+#undef RTX_PAIR_HANDOVER
+    unsigned long long wsegs = segs, wexact = exact, wbox = box_tests, wfilt = (unsigned long long)box_tests + leaf_filters;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        wsegs += __shfl_xor(wsegs, off, 64);
+        wexact += __shfl_xor(wexact, off, 64);
+        wfilt += __shfl_xor(wfilt, off, 64);
+        wbox += __shfl_xor(wbox, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
+        if (wsegs) atomicAdd(&ctr[shard].segments, wsegs);
+        if (wexact) atomicAdd(&ctr[shard].exact_tests, wexact);
+        if (wfilt) atomicAdd(&ctr[shard].filter_tests, wfilt);
+        if (wbox) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, wbox);
+    }
+}
+
 // ---- ordering the survivors for stage 2 ----------------------------------------------------------------------------------
 // A wave's round lasts as long as its longest walk, and how long a walk is depends mostly on how far the ray travels inside
 // the cloud.  The survivors are therefore binned by the distance at which their ray leaves the scene's box (kSortT bins) and
@@ -1115,6 +1427,20 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
         hipLaunchKernelGGL(sph_sort_scatter_kernel, dim3(sblocks), dim3(256), 0, stream, sq, so);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         sq.perm = so.perm;
+    }
+    if (pool_mem && (flags & kSphPair) != 0u) {
+        // stage 2 with two rays per lane (trace_sph_pair_kernel)
+        SphPair pp{};
+        const size_t lanes2 = (size_t)n_cus * kSphWavesPerSimd * kBvhThreads * 2;
+        pp.stride = lanes2;
+        pp.f = reinterpret_cast<double *>(pool_mem);
+        pp.u = reinterpret_cast<uint32_t *>(pp.f + (size_t)kPairF64 * lanes2);
+        const bool pq3 = (sv.bvh_flags & 16u) != 0u && sv.bvh_q3nodes != nullptr && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
+        auto kp = pq3 ? (deep ? trace_sph_pair_kernel<true, true> : trace_sph_pair_kernel<false, true>)
+                      : (deep ? trace_sph_pair_kernel<true, false> : trace_sph_pair_kernel<false, false>);
+        hipLaunchKernelGGL(kp, dim3((uint32_t)n_cus * kPairWaves), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1,
+                           pq3 ? reinterpret_cast<const float4 *>(sv.bvh_q3nodes) : nodes, la, spill, spill_entries, sq, pp);
+        return hipGetLastError();
     }
     if (pool_mem && (flags & kSphPool) != 0u) {
         // stage 2 as a wave-local pool (trace_sph_pool_kernel): the grid is the resident waves, each with its own slots

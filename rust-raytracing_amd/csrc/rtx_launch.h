@@ -44,6 +44,7 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                                     hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr);
 // pool_mem: bvh_spheres_pool2_bytes(n_cus) bytes: stage 2 runs as a wave-local pool of ray slots (flags bit 2: the lock-step form)
 size_t bvh_spheres_pool2_bytes(int n_cus);
+size_t bvh_spheres_pair_bytes(int n_cus);      // flags bit 3: stage 2 with two rays per lane; pool_mem then holds this many bytes
 // (stage1_snapshot: kCounterShards Counters that receive a copy of `counters` as stage 1 left them; stage1_done: recorded
 // after stage 1 -- both only for the two-stage form, both optional: what RtxStats' stage1_* fields are made of)
 

@@ -138,7 +138,7 @@ def test_closed_box_at_two_stage_size_every_ray_survives(gpu):
     import closed_form as cf
     box = cf.closed_box(gpu.OBJECT_DTYPE, 300, seed=8)
     w = h = 1024
-    for tune in (0, gpu.RTX_TUNE_NO_PACKETS):
+    for tune in (0, gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_STAGE2_PAIR, gpu.RTX_TUNE_STAGE2_POOL):
         hnd = hip_scene(gpu, box, cam=((0.3, -0.2, 0.1), (1.0, 0.1, -0.05), 1.5), rays_per_pixel=1, seed=3, tuning=tune).upload(0)
         buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
@@ -326,6 +326,8 @@ def test_spheres_kernel_paths(gpu, oracle):
         out = []
         for kern, tune in ((gpu.RTX_KERNEL_BVH, 0), (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE),
                            (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS),
+                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR),
+                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL | gpu.RTX_TUNE_NO_QNODES),
                            (gpu.RTX_KERNEL_BVH_REGROUP, 0), (gpu.RTX_KERNEL_WAVEFRONT, 0), (gpu.RTX_KERNEL_EXACT, 0)):
             hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, tuning=tune, **cfg).upload(0)
             hnd.set_scratch_limit(scratch)
@@ -563,7 +565,9 @@ def test_ab_knobs_keep_the_bits(gpu):
     knobs = [0, gpu.RTX_TUNE_BVH_CLASSIC, gpu.RTX_TUNE_NO_QNODES, gpu.RTX_TUNE_NO_TILES, 1 << leaf, 2 << leaf, 6 << leaf, 8 << leaf,
              4 << thresh, 48 << thresh, gpu.RTX_TUNE_BVH_MEDIAN, gpu.RTX_TUNE_NO_QNODES | gpu.RTX_TUNE_WF_PURE, 6 << leaf,
              gpu.RTX_TUNE_TWO_STAGE, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_TILES,
-             gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_TWO_STAGE]
+             gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_TWO_STAGE, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR,
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_SORT_SURVIVORS,
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR | gpu.RTX_TUNE_NO_QNODES, gpu.RTX_TUNE_PK_LDS_STACK]
     for tune in knobs:
         for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint)):
             for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT):
@@ -742,6 +746,12 @@ def test_sample_batching_keeps_the_left_fold(gpu, oracle):
     b = buf.cpu().numpy()
     assert st.trace_launches == 4
     assert np.array_equal(a, b)
+    hnd = hip_scene(gpu, objs, **cfg).upload(0)
+    hnd.set_scratch_limit(1 << 50)                          # far above the device's memory: clamped to 3/4 of what is free, not an error
+    buf.zero_()
+    st = hnd.render_rows(300, 200, 0, 1, 200, buf.data_ptr())
+    hnd.close()
+    assert st.trace_launches == 1 and np.array_equal(a, buf.cpu().numpy())
     ref = oracle_render(oracle, objs, 300, 200, **cfg)
     assert max_abs_diff(a, ref) <= ATOL
 
@@ -1219,7 +1229,7 @@ def test_bench_line_contract(gpu):
     """bench.py at a reduced sample count (counters off: they are the next test): one JSON line with the contract's keys,
     strong scaling by default, roofline objects that are fractions of a real ceiling for the value kernel, the LDS sweep
     and the three other configs, a cpu_baseline on the benchmark's own view, and the two kernels' frames bit-identical."""
-    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1", "--no-pmc"])
+    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1,C5band=1", "--no-pmc"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs", "lds_sweep"):
         assert key in d, key
@@ -1241,8 +1251,10 @@ def test_bench_line_contract(gpu):
     assert d["lds_sweep"]["image_identical_to_value_kernel"] is True
     _check_roofline(d["lds_sweep"]["roofline"])
     assert d["speedup_vs_cpu"]["like_for_like_linear_scan"] > 10          # the LDS sweep scans the list as the CPU does
-    assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5"]
-    assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, True]
+    assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5", "C5"]
+    assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, False, True]
+    bal = d["partition_balance"]
+    assert len(bal["segments_per_band"]) == 8 and 1.0 <= bal["max_over_mean"] < 1.1        # blocks of 8 rows round-robin balance the frame
     assert d["other_configs"][1]["band_rate_over_full_frame_rate"] > 0
     for o in d["other_configs"]:
         assert o["value"] > 0 and o["Msegments_per_s"] > 0 and 1.0 <= o["segments_per_primary_ray"] <= 11.0
@@ -1265,7 +1277,7 @@ def test_bench_collects_counters_in_the_run(gpu):
     _check_roofline(r)
     assert r["issued"]["source"].startswith("SQ_THREAD_CYCLES_VALU") and 0.0 < r["lane_utilisation"] <= 1.0
     syms = [k["kernel"] for k in r["kernels"]]
-    assert "trace_sph_packet_kernel" in syms and any(k.endswith("<false, 2>") for k in syms)      # per kernel symbol of the launch
+    assert "trace_sph_packet_kernel" in syms and any(k.startswith("trace_bvh_spheres_kernel<false, 2") for k in syms)      # per kernel symbol of the launch
     assert all("issued_frac" in s_ and "lane_utilisation" in s_ for s_ in r["stages"])
     assert r["traffic"] > 1920 * 1080 * 2 * 24            # at least the sample planes were written
     assert d["hbm_gbs"] == r["hbm_gbs"]
