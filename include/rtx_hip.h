@@ -125,6 +125,11 @@ enum {
     RTX_TUNE_STAGE2_POOL = 1u << 21, /* sphere trees, two stages: stage 2 as a wave-local pool of ray slots (trace_sph_pool_kernel;
                                         an experiment, slower than the lock-step form that ships) */
     RTX_TUNE_STAGE2_PAIR = 1u << 22, /* sphere trees, two stages: stage 2 with two rays per lane (trace_sph_pair_kernel) */
+    RTX_TUNE_BEAMS = 1u << 24,       /* RTX_KERNEL_WAVEFRONT on a pure footprint tree: level 0 as beams (the lanes across nodes, one interval
+                                        test per node for the tile's 64 rays: wf_trace_beam_kernel; an experiment, slower than the
+                                        packets that ship: the leaf records, not the node visits, are what a mesh tile pays for) */
+    RTX_TUNE_NO_CUT = 1u << 23,      /* sphere trees: every round of a lock-step wave lasts until its longest walk ends (round 2's
+                                        form) instead of leaving the last few walkers to continue beside the next segments */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };

@@ -47,8 +47,17 @@ struct SphQueue {
     const uint32_t *perm;                     // stage 2 reads rec[perm[k]] (the survivors ordered by sph_sort_*), or null: queue order
     unsigned long long *count;                // slots reserved by stage 1 = the length stage 2 walks
     unsigned long long capacity;
+    uint32_t cut_walkers;                     // sphere_walk_resumable's threshold for the lock-step kernels (0: walks are never cut)
 };
 constexpr uint32_t kSphQueueChunk = 512;
+#ifndef RTX_SPH_CUT
+#define RTX_SPH_CUT 16
+#endif
+#ifndef RTX_SPH_CUT_DONE
+#define RTX_SPH_CUT_DONE 32
+#endif
+constexpr uint32_t kSphCutWalkers = RTX_SPH_CUT;     // a round's walk is left when fewer lanes than this still walk ...
+constexpr uint32_t kSphCutDone = RTX_SPH_CUT_DONE;   // ... and at least this many of the wave's rays wait for their f64 phase
 
 // Appends the wave's survivors (lanes with `go`) to the queue: consecutive slots of the wave's current reservation; when it
 // runs out mid-way the rest continue in a fresh chunk (one atomic per 512 records), so no slot is wasted except the tail of
@@ -120,6 +129,11 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
     uint32_t ridx = 0;                       // the ray's index in the launch's queue = where its sample goes
     uint32_t first_id = 0;                   // MODE 1: the object of the first hit
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
+    // the walk's state: lives across rounds for a lane whose walk was cut (sphere_walk_resumable)
+    float best_up = __builtin_inff();
+    uint32_t qcnt = 0, nbox = 0, nleaf = 0, w_node = kNone, w_sp = 0;
+    bool overflow = false, walked = false, midwalk = false;
+    const uint32_t cut_walkers = MODE == 1 ? 0u : sq.cut_walkers;       // stage 1 hands every lane a fresh ray each round: no cut there
 
     for (;;) {
         // ---- hand rays to idle lanes: ballot + prefix sum over the wave's local range, one atomic per rv.grab rays
@@ -182,10 +196,10 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
             continue;
         }
 
-        // ---- one segment: closest_object (scene.rs:243-251).  Phase 1, f32 only: walk the tree, collect candidates
-        float best_up = __builtin_inff();
-        uint32_t qcnt = 0, nbox = 0, nleaf = 0;
-        bool overflow = false, walked = false;
+        // ---- one segment: closest_object (scene.rs:243-251).  Phase 1, f32 only: walk the tree, collect candidates.
+        // A lane whose walk was cut (midwalk) comes back with its walk state and goes on where it left
+        const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+        if (!midwalk) { best_up = __builtin_inff(); qcnt = 0; nbox = 0; nleaf = 0; overflow = false; walked = false; w_node = kNone; w_sp = 0; }
         RayX rx;
         if (alive) {
             rx = make_rayx(r.pos, r.dir);
@@ -197,33 +211,35 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                 SphereRay sr;
                 sphere_ray_from(sv, r.pos, r.dir, sr);
                 const V3 dirn = rx.dirn;
+                if (!midwalk) w_node = sv.bvh_root;
                 if constexpr (Q3) {                   // (a far origin walks the same tree with Ray32S's slack instead of an f64 slab test)
                     Ray32 q0;
                     make_ray32(r.pos, dirn, (double)sv.bvh_inv_max, q0);
                     Ray32S q;
                     q.ix = q0.ix; q.iy = q0.iy; q.iz = q0.iz; q.nx = q0.nx; q.ny = q0.ny; q.nz = q0.nz;
                     q.e = ray32_slack(q0.nx, q0.ny, q0.nz, in32);
-                    bvh_traverse_spheres_q3<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, sv.bvh_root, &lds_stack[0][0],
-                                                          lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
-                                                          overflow, nbox, nleaf);
+                    sphere_walk_resumable<STACK, SPILL, true>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
+                                                              lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
+                                                              overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive);
                 } else if (in32) {
                     Ray32 q;
                     make_ray32(r.pos, dirn, (double)sv.bvh_inv_max, q);
-                    bvh_traverse_spheres<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, sv.bvh_root, &lds_stack[0][0],
-                                                       lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
-                                                       overflow, nbox, nleaf);
+                    sphere_walk_resumable<STACK, SPILL, false>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
+                                                               lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
+                                                               overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive);
                 } else {                              // origin far outside the scene: the same walk with an f64 slab test
                     Ray64 q;
                     make_ray64(r.pos, dirn, (double)sv.bvh_inv_max, q);
-                    bvh_traverse_spheres<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, sv.bvh_root, &lds_stack[0][0],
-                                                       lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
-                                                       overflow, nbox, nleaf);
+                    sphere_walk_resumable<STACK, SPILL, false>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
+                                                               lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
+                                                               overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive);
                 }
                 walked = true;
+                midwalk = w_node != kNone;
             }
         }
         // ---- phase 2, f64: exact tests of the candidates that can still be the winner, the shapes outside the tree, ray_hit
-        if (alive) {
+        if (alive && !midwalk) {
             Hit h;
             hit_init(h);
             ++segs;
@@ -1379,6 +1395,7 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
     const bool deep = spill_entries != 0u;
     const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
     SphQueue sq{};
+    sq.cut_walkers = (sv.tuning & RTX_TUNE_NO_CUT) != 0u ? 0u : kSphCutWalkers;
     if (!queue_mem || sv.max_bounces == 0) {     // one stage
         auto kernel = deep ? trace_bvh_spheres_kernel<true, 0> : trace_bvh_spheres_kernel<false, 0>;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter, nodes, la,

@@ -471,6 +471,9 @@ __device__ __forceinline__ void sphere_step(const float4 *__restrict__ nodes, co
 // against box_entry32's fl(b * inv + noi) that is ONE more rounding, of O, at most 2^-24 |o * inv + noi| -- in position terms
 // 2^-24 (|o| + |ray origin|), which the second abs_pad the 64-byte boxes were built with covers (rtx_bvh.h build_q3nodes) and,
 // for the part that scales with a far origin, Ray32S's slack.  Everything after the four entry distances is sphere_step's.
+#ifndef RTX_Q3_SORT64
+#define RTX_Q3_SORT64 1
+#endif
 template <int STACK, bool SPILL, class RAY>
 __device__ __forceinline__ void sphere_step_q3(const float4 *__restrict__ qnodes, const float4 *__restrict__ leaf_f32,
                                                const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
@@ -489,13 +492,20 @@ __device__ __forceinline__ void sphere_step_q3(const float4 *__restrict__ qnodes
     const float e = ray_slack(q);
     float tc[4];
     uint32_t lnk[4], typ[4];
+    // near / far plane of each slab by the sign of the ray's (clamped, never zero or infinite) reciprocal direction, chosen ONCE per
+    // visit on the words that hold the four children's bytes: lo <= hi and the FMA is monotone in the plane, so fl(near * S + O) is
+    // min(x0, x1) of the two-sided form bit for bit, without the 24 v_min / v_max
+    const bool gx = q.ix < 0.0f, gy = q.iy < 0.0f, gz = q.iz < 0.0f;
+    const uint32_t nxw = gx ? hix : lox, fxw = gx ? lox : hix;
+    const uint32_t nyw = gy ? hiy : loy, fyw = gy ? loy : hiy;
+    const uint32_t nzw = gz ? hiz : loz, fzw = gz ? loz : hiz;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float x0 = __builtin_fmaf((float)((lox >> (8 * c)) & 255u), Sx, Ox), x1 = __builtin_fmaf((float)((hix >> (8 * c)) & 255u), Sx, Ox);
-        const float y0 = __builtin_fmaf((float)((loy >> (8 * c)) & 255u), Sy, Oy), y1 = __builtin_fmaf((float)((hiy >> (8 * c)) & 255u), Sy, Oy);
-        const float z0 = __builtin_fmaf((float)((loz >> (8 * c)) & 255u), Sz, Oz), z1 = __builtin_fmaf((float)((hiz >> (8 * c)) & 255u), Sz, Oz);
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float x0 = __builtin_fmaf((float)((nxw >> (8 * c)) & 255u), Sx, Ox), x1 = __builtin_fmaf((float)((fxw >> (8 * c)) & 255u), Sx, Ox);
+        const float y0 = __builtin_fmaf((float)((nyw >> (8 * c)) & 255u), Sy, Oy), y1 = __builtin_fmaf((float)((fyw >> (8 * c)) & 255u), Sy, Oy);
+        const float z0 = __builtin_fmaf((float)((nzw >> (8 * c)) & 255u), Sz, Oz), z1 = __builtin_fmaf((float)((fzw >> (8 * c)) & 255u), Sz, Oz);
+        const float tn = fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f));
+        const float tf = fminf(fminf(x1, y1), z1);
         const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);
         const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);
         typ[c] = lk[c] >> 29;
@@ -555,9 +565,24 @@ __device__ __forceinline__ void sphere_step_q3(const float4 *__restrict__ qnodes
     float key[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) key[c] = (typ[c] == 0u && tc[c] <= best_up) ? tc[c] : __builtin_inff();
+#if RTX_Q3_SORT64
+    // the (key, link) pairs as the high and low word of an f64: same sign, and for these keys (no NaN; +inf is a finite f64 pattern)
+    // the same order as the f32 key's, ties by link -- so a compare-exchange is v_min_f64 + v_max_f64 instead of v_cmp + 4 v_cndmask.
+    // (Written as instructions: the pairs are not canonical f64 values and fmin() would first quiet them.)
+    double kd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kd[c] = __hiloint2double((int)__float_as_uint(key[c]), (int)lnk[c]);
+#define RTX_CSWAP(i, j) { double lo_, hi_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(kd[i]), "v"(kd[j])); \
+                          asm("v_max_f64 %0, %1, %2" : "=v"(hi_) : "v"(kd[i]), "v"(kd[j])); kd[i] = lo_; kd[j] = hi_; }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { key[c] = __uint_as_float((uint32_t)__double2hiint(kd[c])); lnk[c] = (uint32_t)__double2loint(kd[c]); }
+#else
 #define RTX_CSWAP(i, j) { if (key[j] < key[i]) { float tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = lnk[i]; lnk[i] = lnk[j]; lnk[j] = tl; } }
     RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
+#endif
     const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
                            (key[3] < __builtin_inff() ? 1u : 0u);
     if (sp + 3u <= (uint32_t)STACK) {
@@ -601,6 +626,33 @@ __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ 
     while (node != kNone)
         sphere_step<STACK, SPILL>(nodes, leaf_f32, leaf_prims, q, sr, node, sp, lds_stack, lds_q, tid, spill, spill_entries,
                                   spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+}
+
+// The same walks, resumable: `node` / `sp` (and the caller's best_up, qcnt, nbox, nleaf, the lane's LDS stack and candidate
+// columns) are the whole state of a walk, so a wave may leave the loop while a few lanes are still in it and come back to it
+// after the f64 phase of the others.  The loop is left when fewer than `cut_walkers` of its lanes still walk and at least
+// `cut_done` of the wave's `n_alive` rays wait for their f64 phase (wave-uniform: the ballot is over the lanes still in the
+// loop); cut_walkers = 0 never cuts.  A round of a lock-step wave lasts as long as its longest walk -- ~55 visits against 21
+// on average (lane utilisation 0.39) --: cutting the tail lets the many finished lanes go on while the few long walks
+// continue, a visit later, beside the next segments.
+template <int STACK, bool SPILL, bool Q3, class RAY>
+__device__ __forceinline__ void sphere_walk_resumable(const float4 *__restrict__ nodes, const float4 *__restrict__ leaf_f32,
+                                                      const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
+                                                      uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                                      uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                      size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
+                                                      uint32_t &nbox, uint32_t &nleaf, uint32_t cut_walkers, uint32_t cut_done, uint32_t n_alive)
+{
+    while (node != kNone) {
+        if constexpr (Q3)
+            sphere_step_q3<STACK, SPILL>(nodes, leaf_f32, leaf_prims, q, sr, node, sp, lds_stack, lds_q, tid, spill, spill_entries,
+                                         spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+        else
+            sphere_step<STACK, SPILL>(nodes, leaf_f32, leaf_prims, q, sr, node, sp, lds_stack, lds_q, tid, spill, spill_entries,
+                                      spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
+        const uint32_t still = (uint32_t)__popcll(__ballot(node != kNone));
+        if (still < cut_walkers && n_alive - still >= cut_done) break;
+    }
 }
 
 template <int STACK, bool SPILL, class RAY>

@@ -458,6 +458,229 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
     }
 }
 
+// ---- the walk of level 0 as beams ------------------------------------------------------------------------------------------
+// The packet walk above opens ONE node per step for the whole wave: every lane tests its ray against the four rectangles, the
+// ordering and the stack are scalar code -- 369 such steps per C3 tile, ~60 VALU and ~70 SALU instructions each, and the kernel
+// is bound by the CU's one scalar pipe.  But WHICH nodes a tile opens hardly depends on the lane: its 64 rays leave (almost) one
+// point a few pixels apart.  So here the lanes test different NODES against the tile's BEAM: a step takes up to 16 nodes off the
+// wave's stack, lane l tests child l & 3 of node l >> 2 (its rectangle, link and count: three quad-coalesced loads) against
+// interval bounds of all the tile's rays at once, the interior children that pass go back to the stack (ballot + mbcnt), and the
+// leaves that pass are handled as in the packet walk: records at a wave-uniform address through the scalar cache, every lane
+// filtering and bounding them for ITS ray behind ITS own test of the leaf's rectangle.  ~23 steps per C3 tile instead of 369.
+//
+// The beam test is rect_entry32 with every term replaced by a bound over the tile: a lane's slab distances are
+// fl(b * i + n) with its i in [i_min, i_max] and n in [n_min, n_max] (wave reductions over the lanes that walk), so
+// min(fl(b i_min + n_min), fl(b i_max + n_min)) <= each of them <= max(fl(b i_min + n_max), fl(b i_max + n_max)) -- b * i is
+// linear in i and rounding is monotone --, for either plane of the slab and any mix of signs; entry / exit / widening / slack /
+// best_up are then combined exactly as a lane does, with the largest slack and the largest best_up.  Whatever a lane's own test
+// accepts the beam accepts: a lane sees every leaf its own walk would open, in some order, and collects every candidate with
+// t_lo <= its best_up -- the exact tests decide as always.  What is given up is the order (no nearest-first: a tile of rays that
+// all end early still sees the beam's whole length until every lane has a certain hit).
+// MEASURED AND NOT SHIPPED (RTX_TUNE_BEAMS selects it; LAB_NOTEBOOK R3.8): bit-identical, and slower -- C3 39.0 against 36.2 ms,
+// C5 band 80.3 against 52.2.  The premise was wrong: a mesh tile pays for its leaf records (the wave opens ~400 leaves = 2000
+// records per C3 tile, every one filtered by all 64 lanes), not for its node visits, and the beam adds the leaves an ordered walk
+// never reaches once its rays have ended (C5: most primary rays end early).
+constexpr int kBeamStack = 512;                                    // wave-uniform stack entries in LDS; a step that could overflow it opens fewer nodes
+constexpr int kBeamNodes = 16;                                     // nodes opened per step: 64 children, one per lane
+#ifndef RTX_BEAM_WAVES
+#define RTX_BEAM_WAVES 6
+#endif
+constexpr int kBeamWaves = RTX_BEAM_WAVES;                         // workgroups per CU
+
+__device__ __forceinline__ float beam_wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float beam_wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+struct Beam { float ixa, ixb, iya, iyb, nxa, nxb, nya, nyb, e, best; };      // a: minimum, b: maximum over the tile's walking lanes
+
+__device__ __forceinline__ bool beam_enters_rect(const float4 r4, const Beam &b)
+{
+    const float lx = fminf(fminf(__builtin_fmaf(r4.x, b.ixa, b.nxa), __builtin_fmaf(r4.x, b.ixb, b.nxa)),
+                           fminf(__builtin_fmaf(r4.z, b.ixa, b.nxa), __builtin_fmaf(r4.z, b.ixb, b.nxa)));
+    const float ux = fmaxf(fmaxf(__builtin_fmaf(r4.x, b.ixa, b.nxb), __builtin_fmaf(r4.x, b.ixb, b.nxb)),
+                           fmaxf(__builtin_fmaf(r4.z, b.ixa, b.nxb), __builtin_fmaf(r4.z, b.ixb, b.nxb)));
+    const float ly = fminf(fminf(__builtin_fmaf(r4.y, b.iya, b.nya), __builtin_fmaf(r4.y, b.iyb, b.nya)),
+                           fminf(__builtin_fmaf(r4.w, b.iya, b.nya), __builtin_fmaf(r4.w, b.iyb, b.nya)));
+    const float uy = fmaxf(fmaxf(__builtin_fmaf(r4.y, b.iya, b.nyb), __builtin_fmaf(r4.y, b.iyb, b.nyb)),
+                           fmaxf(__builtin_fmaf(r4.w, b.iya, b.nyb), __builtin_fmaf(r4.w, b.iyb, b.nyb)));
+    const float tn = fmaxf(fmaxf(lx, ly), 0.0f);
+    const float tf = fminf(ux, uy);
+    const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -b.e);
+    const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, b.e);
+    return (tn_lo <= tf_hi) && (tn_lo <= b.best);
+}
+
+__global__ __launch_bounds__(kBvhThreads, kBeamWaves) void wf_trace_beam_kernel(const WfState st, Counters *__restrict__ ctr,
+                                                                                const float4 *__restrict__ nodes, const MeshArrays ma,
+                                                                                uint32_t root)
+{
+    __shared__ uint32_t bm_stack[kBvhThreads >> 6][kBeamStack];
+    __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];
+    uint32_t *const lq = &lds_q[0][0];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t *const stk = &bm_stack[tid >> 6][0];
+    const unsigned long long n_queue = st.count[0];
+    const unsigned long long n_tiles = (n_queue + 63ull) >> 6;
+    const WfRec *__restrict__ recs = st.rec[0];
+    unsigned long long *const head = &st.work[0];                  // counts tiles here
+    unsigned long long grab = n_tiles / ((unsigned long long)gridDim.x * (kBvhThreads >> 6) * 8ull);
+    grab = grab > 8ull ? 8ull : (grab < 1ull ? 1ull : grab);
+    unsigned long long t_next = 0, t_end = 0;
+    unsigned long long box_tests = 0, leaf_filters = 0;
+    const PkConst4 ctri = pk_const(ma.tri_f32), cgeo = pk_const(ma.tri_geo);
+    const float inf = __builtin_inff();
+
+    for (;;) {
+        if (t_next >= t_end) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(head, grab);
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                   __builtin_amdgcn_readfirstlane((uint32_t)base);
+            if (base >= n_tiles) break;
+            t_next = base;
+            t_end = base + grab < n_tiles ? base + grab : n_tiles;
+        }
+        const unsigned long long p = (t_next << 6) + lane;
+        t_next += 1;
+        WfRec w;
+        w.ridx = kNone; w.best_up = 0.f;
+        w.px = w.py = w.pz = w.dx = w.dy = w.dz = w.ix = w.iy = w.iz = w.nx = w.ny = w.nz = w.A = w.slack = 0.f;
+        if (p < n_queue) w = recs[p];
+        const bool valid = w.ridx != kNone;
+        const bool walk = valid && w.best_up == w.best_up;         // (NaN: no f32 walk for this origin)
+        bool overflow = valid && !walk, extra = false;
+        Ray32S q;
+        TriFilterParams tp;
+        q.ix = w.ix; q.iy = w.iy; q.iz = w.iz; q.nx = w.nx; q.ny = w.ny; q.nz = w.nz; q.e = w.slack;
+        tp.dx = w.dx; tp.dy = w.dy; tp.dz = w.dz; tp.npx = -w.px; tp.npy = -w.py; tp.npz = -w.pz; tp.A = w.A; tp.pad = 0.f;
+        float best_up = walk ? w.best_up : -inf;                    // -inf: this lane enters nothing
+        uint32_t qcnt = 0, nbox = 0, nleaf = 0;
+        uint32_t sp = 0;
+        Beam bm;
+        bm.ixa = bm.ixb = bm.iya = bm.iyb = bm.nxa = bm.nxb = bm.nya = bm.nyb = bm.e = 0.0f; bm.best = -inf;
+        if (__ballot(walk) != 0ull) {
+            bm.ixa = beam_wave_min(walk ? w.ix : inf); bm.ixb = beam_wave_max(walk ? w.ix : -inf);
+            bm.iya = beam_wave_min(walk ? w.iy : inf); bm.iyb = beam_wave_max(walk ? w.iy : -inf);
+            bm.nxa = beam_wave_min(walk ? w.nx : inf); bm.nxb = beam_wave_max(walk ? w.nx : -inf);
+            bm.nya = beam_wave_min(walk ? w.ny : inf); bm.nyb = beam_wave_max(walk ? w.ny : -inf);
+            bm.e = beam_wave_max(walk ? w.slack : 0.0f);
+            bm.best = beam_wave_max(best_up);
+            if (lane == 0) stk[0] = root & ~kBvhFlatNode;
+            sp = 1;
+        }
+        while (sp != 0u) {
+            // how many nodes this step opens: opening k leaves at most sp + 3 k entries
+            uint32_t k = sp < (uint32_t)kBeamNodes ? sp : (uint32_t)kBeamNodes;
+            const uint32_t room = ((uint32_t)kBeamStack - sp) / 3u;
+            k = k < room ? k : room;
+            if (k == 0u) {                                          // a tree deeper than the stack can follow: every shape for these rays
+                if (walk) { overflow = true; best_up = -inf; }
+                break;
+            }
+            const uint32_t slot = lane >> 2, c = lane & 3u;
+            const bool act = slot < k;
+            float4 rc = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t lk = 0u, ct = 0xFFFFFFFFu;
+            if (act) {
+                const uint32_t nd = stk[sp - 1u - slot];
+                const float4 *np = nodes + 8 * (size_t)nd;             // a footprint node: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
+                rc = np[c];
+                lk = reinterpret_cast<const uint32_t *>(np + 4)[c];
+                ct = reinterpret_cast<const uint32_t *>(np + 5)[c];
+            }
+            sp -= k;
+            const bool in = act && ct != 0xFFFFFFFFu && beam_enters_rect(rc, bm);
+            if (act) nbox += 1;
+            const bool inner = in && ct == 0u;
+            const unsigned long long im = RTX_PK_BALLOT(inner);
+            if (inner) stk[sp + bvh_mbcnt(im)] = lk & ~kBvhFlatNode;
+            sp += (uint32_t)__popcll(im);
+            unsigned long long lm = RTX_PK_BALLOT(in && ct != 0u);
+            bool bounded = false;
+            while (lm != 0ull) {
+                const int l = __ffsll((long long)lm) - 1;
+                lm &= lm - 1ull;
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)lk, l);
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)ct, l) & 0xFFFFu;
+                float4 lr;
+                lr.x = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rc.x), l));
+                lr.y = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rc.y), l));
+                lr.z = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rc.z), l));
+                lr.w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rc.w), l));
+                const bool lin = rect_entry32(lr, q, best_up) < inf;           // the lane's own test of the leaf's rectangle
+                if (best_up >= 0.0f) nbox += 1;
+                if (RTX_PK_BALLOT(lin) == 0ull) continue;
+                if (lin) nleaf += n;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const PkConst4 rp = ctri + 2 * (size_t)(first + j);
+                    const float4 A = rp[0], B = rp[1];
+                    const bool pass = lin && (int)tri_filter_sign(A, B, tp) >= 0;
+                    if (RTX_PK_BALLOT(pass) == 0ull) continue;
+                    const PkConst4 gp = cgeo + 2 * (size_t)(first + j);
+                    const float4 g0 = gp[0], g1 = gp[1];
+                    if (pass) {
+                        float thi;
+                        const float tlo = tri_bounds(A, g0, g1, tp, thi);
+                        if (tlo <= best_up && tlo < inf) {
+                            bounded = bounded || thi < best_up;
+                            best_up = fminf(best_up, thi);
+                            if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {       // more live candidates than the queue holds:
+                                if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;   // to the overflow list
+                                else { overflow = true; best_up = -inf; }                  // (full: the shade kernel tests every shape for this ray)
+                            }
+                            if (!overflow) {
+                                lq[(size_t)qcnt * kBvhThreads + tid] = (first + j) | kQueueTri;
+                                lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                                qcnt += 1;
+                            }
+                        }
+                    }
+                }
+            }
+            if (RTX_PK_BALLOT(bounded) != 0ull) bm.best = beam_wave_max(best_up);      // the beam ends where its last ray ends
+        }
+        if (p < n_queue) {
+            WfCand c;
+            uint32_t k = 0;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) c.e[e] = 0u;
+#pragma unroll
+            for (int e = 0; e < kMeshQueue; ++e) {
+                if ((uint32_t)e < qcnt && __uint_as_float(lq[(size_t)(kMeshQueue + e) * kBvhThreads + tid]) <= best_up) {
+                    const uint32_t v = lq[(size_t)e * kBvhThreads + tid];
+                    c.e[0] = k == 0u ? v : c.e[0]; c.e[1] = k == 1u ? v : c.e[1]; c.e[2] = k == 2u ? v : c.e[2];
+                    c.e[3] = k == 3u ? v : c.e[3]; c.e[4] = k == 4u ? v : c.e[4]; c.e[5] = k == 5u ? v : c.e[5];
+                    k += 1;
+                }
+            }
+            c.e[6] = w.ridx;
+            c.count = !valid ? kWfDead : (overflow ? kWfFallback : (k | (extra ? kWfExtra : 0u)));
+            st.cand[p] = c;
+        }
+        box_tests += nbox; leaf_filters += nleaf;
+    }
+    unsigned long long filt = box_tests + leaf_filters;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        filt += __shfl_xor(filt, off, 64);
+        box_tests += __shfl_xor(box_tests, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);
+    }
+}
+
 // ---- closest_object's exact part, ray_hit, the next segment's set-up ---------------------------------------------------------
 __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
                                                                   const WfState st, uint32_t level, double *__restrict__ samples,
@@ -690,8 +913,13 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     if (joint && !packets) return hipErrorInvalidValue;      // (wavefront_mesh_supported() keeps the caller from asking)
     const float cmax_ru = std::nextafterf((float)sv.sphere_cmax, INFINITY);
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * (joint ? kPkWavesJoint : kPkWaves));
+    // on request, a pure footprint tree: the tile's rays as ONE beam, the lanes across nodes (wf_trace_beam_kernel); any depth
+    const bool beams = rv.tiles_x != 0u && !joint && (sv.tuning & RTX_TUNE_NO_PACKETS) == 0u && (sv.tuning & RTX_TUNE_BEAMS) != 0u;
+    const uint32_t beam_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kBeamWaves);
     auto level_fn = [&](const WfState &sk, uint32_t level) {
-        if (level == 0u && packets) {
+        if (level == 0u && beams) {
+            hipLaunchKernelGGL(wf_trace_beam_kernel, dim3(beam_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root);
+        } else if (level == 0u && packets) {
             const uint32_t lane_stack = 3u * sv.bvh_depth + 2u <= (uint32_t)kPkLaneStack && (sv.tuning & RTX_TUNE_PK_LDS_STACK) == 0u ? 1u : 0u;
             if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
             else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
