@@ -20,7 +20,10 @@
 
 namespace rtx {
 
-constexpr int kSphWavesPerSimd = 4;          // = workgroups per CU (4 waves each)
+#ifndef RTX_SPH_WAVES
+#define RTX_SPH_WAVES 4
+#endif
+constexpr int kSphWavesPerSimd = RTX_SPH_WAVES;          // = workgroups per CU (4 waves each)
 constexpr int kSphStack = 30;                // LDS stack entries per lane: (30 + 1 sink row + 2 * kSphQueue queue rows) KB per workgroup
 
 // Two stages.  A wave's round lasts as long as its longest walk.  Primary rays (an 8x8 tile per wave: coherent, short
