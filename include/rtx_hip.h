@@ -128,6 +128,8 @@ enum {
     RTX_TUNE_BEAMS = 1u << 24,       /* RTX_KERNEL_WAVEFRONT on a pure footprint tree: level 0 as beams (the lanes across nodes, one interval
                                         test per node for the tile's 64 rays: wf_trace_beam_kernel; an experiment, slower than the
                                         packets that ship: the leaf records, not the node visits, are what a mesh tile pays for) */
+    RTX_TUNE_INLINE_LEAVES = 1u << 25, /* sphere trees, 64-byte nodes: a node's leaf children are bounded inside the node visit (the
+                                        earlier form) instead of being pushed and visited when popped, leaf visits apart from node visits */
     RTX_TUNE_NO_CUT = 1u << 23,      /* sphere trees: every round of a lock-step wave lasts until its longest walk ends (round 2's
                                         form) instead of leaving the last few walkers to continue beside the next segments */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which

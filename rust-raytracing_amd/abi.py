@@ -24,6 +24,7 @@ RTX_TUNE_STAGE2_POOL = 1 << 21
 RTX_TUNE_STAGE2_PAIR = 1 << 22
 RTX_TUNE_NO_CUT = 1 << 23
 RTX_TUNE_BEAMS = 1 << 24
+RTX_TUNE_INLINE_LEAVES = 1 << 25
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)

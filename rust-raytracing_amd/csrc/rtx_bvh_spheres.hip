@@ -59,6 +59,10 @@ constexpr uint32_t kSphQueueChunk = 512;
 #ifndef RTX_SPH_CUT_DONE
 #define RTX_SPH_CUT_DONE 32
 #endif
+#ifndef RTX_SPH_LEAF_LANES
+#define RTX_SPH_LEAF_LANES 8
+#endif
+constexpr uint32_t kSphLeafLanes = RTX_SPH_LEAF_LANES;   // a leaf visit runs when this many lanes of the wave hold a leaf (or all that walk do)
 constexpr uint32_t kSphCutWalkers = RTX_SPH_CUT;     // a round's walk is left when fewer lanes than this still walk ...
 constexpr uint32_t kSphCutDone = RTX_SPH_CUT_DONE;   // ... and at least this many of the wave's rays wait for their f64 phase
 
@@ -103,7 +107,7 @@ __device__ __forceinline__ void sph_queue_close(const SphQueue &sq, uint32_t lan
         if (s < sq.capacity) sq.rec[s].ridx = kNone;
 }
 
-template <bool SPILL, int MODE, bool Q3 = false>          // Q3: `nodes` are the 64-byte nodes (rtx_bvh.h BvhQ3Node), 4 float4 each
+template <bool SPILL, int MODE, int Q3 = 0>               // Q3: `nodes` are the 64-byte nodes (rtx_bvh.h BvhQ3Node), 4 float4 each; 2: leaf visits apart (sphere_walk_phased), 1: inside the node visit
 __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spheres_kernel(const SceneView *__restrict__ svp,
                                                                              const RowsView *__restrict__ rvp,
                                                                              double *__restrict__ samples, Counters *__restrict__ ctr,
@@ -221,9 +225,14 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                     Ray32S q;
                     q.ix = q0.ix; q.iy = q0.iy; q.iz = q0.iz; q.nx = q0.nx; q.ny = q0.ny; q.nz = q0.nz;
                     q.e = ray32_slack(q0.nx, q0.ny, q0.nz, in32);
-                    sphere_walk_resumable<STACK, SPILL, true>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
-                                                              lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
-                                                              overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive);
+                    if constexpr (Q3 == 2)            // node visits and leaf visits apart (the default)
+                        sphere_walk_phased<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
+                                                         lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
+                                                         overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive, kSphLeafLanes);
+                    else
+                        sphere_walk_resumable<STACK, SPILL, true>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
+                                                                  lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
+                                                                  overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive);
                 } else if (in32) {
                     Ray32 q;
                     make_ray32(r.pos, dirn, (double)sv.bvh_inv_max, q);
@@ -1399,10 +1408,15 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
     const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
     SphQueue sq{};
     sq.cut_walkers = (sv.tuning & RTX_TUNE_NO_CUT) != 0u ? 0u : kSphCutWalkers;
-    if (!queue_mem || sv.max_bounces == 0) {     // one stage
-        auto kernel = deep ? trace_bvh_spheres_kernel<true, 0> : trace_bvh_spheres_kernel<false, 0>;
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter, nodes, la,
-                           spill, spill_entries, sq);
+    const bool q3 = (sv.bvh_flags & 16u) != 0u && sv.bvh_q3nodes != nullptr && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
+    const bool inl = (sv.tuning & RTX_TUNE_INLINE_LEAVES) != 0u;
+    const float4 *q3nodes = reinterpret_cast<const float4 *>(sv.bvh_q3nodes);
+    if (!queue_mem || sv.max_bounces == 0) {     // one stage (small launches): per-lane walks over the 64-byte nodes as in stage 2
+        auto kernel = !q3 ? (deep ? trace_bvh_spheres_kernel<true, 0> : trace_bvh_spheres_kernel<false, 0>)
+                          : inl ? (deep ? trace_bvh_spheres_kernel<true, 0, 1> : trace_bvh_spheres_kernel<false, 0, 1>)
+                                : (deep ? trace_bvh_spheres_kernel<true, 0, 2> : trace_bvh_spheres_kernel<false, 0, 2>);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
+                           q3 ? q3nodes : nodes, la, spill, spill_entries, sq);
         return hipGetLastError();
     }
     // ---- two stages: carve the queue (256-byte boundaries), zero its two counters
@@ -1477,11 +1491,11 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                            pq3 ? reinterpret_cast<const float4 *>(sv.bvh_q3nodes) : nodes, la, spill, pool_spill, sq, pool);
         return hipGetLastError();
     }
-    const bool q3 = (sv.bvh_flags & 16u) != 0u && sv.bvh_q3nodes != nullptr && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
     if (q3) {       // the queue-fed stage walks per lane over the 64-byte nodes: half the L1 requests per visit
-        auto k2 = deep ? trace_bvh_spheres_kernel<true, 2, true> : trace_bvh_spheres_kernel<false, 2, true>;
+        auto k2 = inl ? (deep ? trace_bvh_spheres_kernel<true, 2, 1> : trace_bvh_spheres_kernel<false, 2, 1>)
+                      : (deep ? trace_bvh_spheres_kernel<true, 2, 2> : trace_bvh_spheres_kernel<false, 2, 2>);
         hipLaunchKernelGGL(k2, dim3(blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1,
-                           reinterpret_cast<const float4 *>(sv.bvh_q3nodes), la, spill, spill_entries, sq);
+                           q3nodes, la, spill, spill_entries, sq);
         return hipGetLastError();
     }
     auto k2 = deep ? trace_bvh_spheres_kernel<true, 2> : trace_bvh_spheres_kernel<false, 2>;

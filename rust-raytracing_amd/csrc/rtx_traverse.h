@@ -628,6 +628,170 @@ __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ 
                                   spill_stride, glane, best_up, qcnt, overflow, nbox, nleaf);
 }
 
+// ---- the walk in two phases: node visits and leaf visits apart -----------------------------------------------------------------
+// sphere_step_q3 handles the leaves a node's children turn out to be INSIDE the visit, under the mask of the lanes that have one.
+// A lane has such a leaf in 8 % of its visits -- and a wave with 41 walking lanes therefore in 97 % of its iterations: the ~65
+// instructions of leaf code (bounds, candidate queue) are issued in nearly every iteration for two or three lanes (measured,
+// LAB_NOTEBOOK R3.11).  Here a leaf child is pushed like any other child -- the stack holds the 32-bit links, type bits and all,
+// in entry order -- and its sphere records are bounded when it is POPPED.  An iteration of the wave is then either a node visit (for
+// the lanes whose current entry is a node; the lanes holding a leaf wait) or a leaf visit (the other way round), chosen for the
+// wave: leaves when at least `leaf_lanes` lanes hold one, or nobody holds a node.  Both kinds of code run with the lanes that
+// need them, the node visit has no leaf code in it, and the leaves come in distance order with the nodes.
+// Every leaf a ray enters is still bounded with the lane's own best_up before the walk ends: same candidates for the exact tests.
+template <int STACK, bool SPILL, class RAY>
+__device__ __forceinline__ void sphere_node_step_q3(const float4 *__restrict__ qnodes, const RAY &q, uint32_t &node, uint32_t &sp,
+                                                    uint32_t *lds_stack, uint32_t tid, uint32_t *__restrict__ spill,
+                                                    uint32_t spill_entries, size_t spill_stride, size_t glane, float best_up,
+                                                    bool &overflow, uint32_t &nbox)
+{
+    const float4 *np = qnodes + 4 * (size_t)node;
+    const float4 h0 = np[0], h1 = np[1], h2 = np[2], h3 = np[3];
+    const float Sx = h0.w * q.ix, Sy = h1.x * q.iy, Sz = h1.y * q.iz;
+    const float Ox = __builtin_fmaf(h0.x, q.ix, q.nx), Oy = __builtin_fmaf(h0.y, q.iy, q.ny), Oz = __builtin_fmaf(h0.z, q.iz, q.nz);
+    const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);
+    const uint32_t hix = __float_as_uint(h2.y), hiy = __float_as_uint(h2.z), hiz = __float_as_uint(h2.w);
+    const uint32_t lk[4] = { __float_as_uint(h3.x), __float_as_uint(h3.y), __float_as_uint(h3.z), __float_as_uint(h3.w) };
+    const float e = ray_slack(q);
+    const bool gx = q.ix < 0.0f, gy = q.iy < 0.0f, gz = q.iz < 0.0f;                 // (sphere_step_q3: near / far plane by the sign)
+    const uint32_t nxw = gx ? hix : lox, fxw = gx ? lox : hix;
+    const uint32_t nyw = gy ? hiy : loy, fyw = gy ? loy : hiy;
+    const uint32_t nzw = gz ? hiz : loz, fzw = gz ? loz : hiz;
+    double kd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float x0 = __builtin_fmaf((float)((nxw >> (8 * c)) & 255u), Sx, Ox), x1 = __builtin_fmaf((float)((fxw >> (8 * c)) & 255u), Sx, Ox);
+        const float y0 = __builtin_fmaf((float)((nyw >> (8 * c)) & 255u), Sy, Oy), y1 = __builtin_fmaf((float)((fyw >> (8 * c)) & 255u), Sy, Oy);
+        const float z0 = __builtin_fmaf((float)((nzw >> (8 * c)) & 255u), Sz, Oz), z1 = __builtin_fmaf((float)((fzw >> (8 * c)) & 255u), Sz, Oz);
+        const float tn = fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f));
+        const float tf = fminf(fminf(x1, y1), z1);
+        const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);
+        const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);
+        const float key = (tn_lo <= tf_hi && tn_lo <= best_up && lk[c] < 0xE0000000u) ? tn_lo : __builtin_inff();   // (type 7: an empty slot)
+        kd[c] = __hiloint2double((int)__float_as_uint(key), (int)lk[c]);
+    }
+    nbox += 4;
+    // (key, link) pairs ordered as f64 values (sphere_step_q3)
+#define RTX_CSWAP(i, j) { double lo_, hi_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(kd[i]), "v"(kd[j])); \
+                          asm("v_max_f64 %0, %1, %2" : "=v"(hi_) : "v"(kd[i]), "v"(kd[j])); kd[i] = lo_; kd[j] = hi_; }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    float key[4];
+    uint32_t lnk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { key[c] = __uint_as_float((uint32_t)__double2hiint(kd[c])); lnk[c] = (uint32_t)__double2loint(kd[c]); }
+    const uint32_t npush = (key[1] < __builtin_inff() ? 1u : 0u) + (key[2] < __builtin_inff() ? 1u : 0u) +
+                           (key[3] < __builtin_inff() ? 1u : 0u);
+    if (sp + 3u <= (uint32_t)STACK) {
+#pragma unroll
+        for (uint32_t i = 1; i <= 3; ++i) {
+            const uint32_t row = i <= npush ? sp + npush - i : (uint32_t)STACK;
+            lds_stack[(size_t)row * kBvhThreads + tid] = lnk[i];
+        }
+        sp += npush;
+    } else {
+#define RTX_PUSH(v)                                                                                  \
+        {                                                                                            \
+            if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = (v); sp += 1; } \
+            else if (SPILL && sp - (uint32_t)STACK < spill_entries) {                                \
+                spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane] = (v); sp += 1;         \
+            } else overflow = true;                                                                  \
+        }
+        if (key[3] < __builtin_inff()) RTX_PUSH(lnk[3])
+        if (key[2] < __builtin_inff()) RTX_PUSH(lnk[2])
+        if (key[1] < __builtin_inff()) RTX_PUSH(lnk[1])
+#undef RTX_PUSH
+    }
+    node = key[0] < __builtin_inff() ? lnk[0] : kNone;
+    if (node == kNone && sp != 0u) {
+        sp -= 1;
+        node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+    }
+}
+
+// The leaf `ref` (type << 29 | first record, type = its 1..6 spheres): sphere_step's bounds for each record, then the next entry.
+template <int STACK, bool SPILL>
+__device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf_f32, const uint32_t *__restrict__ leaf_prims,
+                                                 const SphereRay &sr, uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                                 uint32_t tid, uint32_t *__restrict__ spill, size_t spill_stride, size_t glane,
+                                                 float &best_up, uint32_t &qcnt, bool &overflow, uint32_t &nleaf)
+{
+    const uint32_t first = node & 0x1FFFFFFFu, n = node >> 29;
+    for (uint32_t k = 0; k < n; ++k) {
+        const float4 rec = leaf_f32[first + k];                              // {c - centre, r}
+        const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+        const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+        const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
+        const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+        const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+        const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+        const float Dp = Dl + G;
+        if (Dp >= 0.0f) {                                                     // the exact test cannot be excluded (sphere_step)
+            const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+            const float Dm = Dl - G;
+            const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+            if (tlo <= best_up && !(thi < 0.0f)) {
+                if (tlo > sr.K) best_up = fminf(best_up, thi);
+                if (qcnt == (uint32_t)kSphQueue) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int e2 = 0; e2 < kSphQueue; ++e2) {
+                        const uint32_t ie = lds_q[(size_t)e2 * kBvhThreads + tid];
+                        const uint32_t te = lds_q[(size_t)(kSphQueue + e2) * kBvhThreads + tid];
+                        if (__uint_as_float(te) <= best_up) {
+                            lds_q[(size_t)w * kBvhThreads + tid] = ie;
+                            lds_q[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                            w += 1;
+                        }
+                    }
+                    qcnt = w;
+                }
+                if (qcnt == (uint32_t)kSphQueue) overflow = true;
+                else {
+                    lds_q[(size_t)qcnt * kBvhThreads + tid] = leaf_prims[first + k];
+                    lds_q[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                    qcnt += 1;
+                }
+            }
+        }
+    }
+    nleaf += n;
+    node = kNone;
+    if (sp != 0u) {
+        sp -= 1;
+        node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
+                                                : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
+    }
+}
+
+// The resumable walk (below) in this form.  `node` is a link: type 0 = a node, 1..6 = a leaf; kNone = the walk has ended.
+// (Measured and dropped, LAB_NOTEBOOK R3.11: a lane that pops a leaf putting it aside in a register and going on with the next
+// entry instead of waiting for the wave's next leaf visit -- 54.8 against 54.6 ms, 1 % more box tests from the later best_up.)
+template <int STACK, bool SPILL, class RAY>
+__device__ __forceinline__ void sphere_walk_phased(const float4 *__restrict__ qnodes, const float4 *__restrict__ leaf_f32,
+                                                   const uint32_t *__restrict__ leaf_prims, const RAY &q, const SphereRay &sr,
+                                                   uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                                   uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                   size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
+                                                   uint32_t &nbox, uint32_t &nleaf, uint32_t cut_walkers, uint32_t cut_done, uint32_t n_alive,
+                                                   uint32_t leaf_lanes)
+{
+    while (node != kNone) {
+        const bool at_leaf = (node >> 29) != 0u;
+        const unsigned long long lm = __ballot(at_leaf), am = __ballot(true);
+        if ((uint32_t)__popcll(lm) >= leaf_lanes || lm == am) {
+            if (at_leaf)
+                sphere_leaf_step<STACK, SPILL>(leaf_f32, leaf_prims, sr, node, sp, lds_stack, lds_q, tid, spill, spill_stride, glane,
+                                               best_up, qcnt, overflow, nleaf);
+        } else if (!at_leaf) {
+            sphere_node_step_q3<STACK, SPILL>(qnodes, q, node, sp, lds_stack, tid, spill, spill_entries, spill_stride, glane, best_up,
+                                              overflow, nbox);
+        }
+        const uint32_t still = (uint32_t)__popcll(__ballot(node != kNone));
+        if (still < cut_walkers && n_alive - still >= cut_done) break;
+    }
+}
+
 // The same walks, resumable: `node` / `sp` (and the caller's best_up, qcnt, nbox, nleaf, the lane's LDS stack and candidate
 // columns) are the whole state of a walk, so a wave may leave the loop while a few lanes are still in it and come back to it
 // after the f64 phase of the others.  The loop is left when fewer than `cut_walkers` of its lanes still walk and at least
