@@ -80,8 +80,9 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                 3: "trace_mixed_kernel + verify",
                 4: "flat 4-wide BVH (sphere tree: from 2^20 rays per launch on in two stages -- stage 1 trace_sph_packet_kernel: the "
                    "primary rays, one wave-uniform f32 walk per 8x8 tile through the scalar cache, exact f64 tests + ray_hit with all "
-                   "lanes; stage 2 trace_bvh_spheres_kernel<.,2>: the rays that survived their first hit, from a queue of 64-byte "
-                   "records, lock-step per-lane walks -- both counted into the launch; trace_bvh_kernel when the tree holds triangles)",
+                   "lanes; stage 2 trace_bvh_spheres_kernel<.,2,2>: the rays that survived their first hit, from a queue of 64-byte "
+                   "records, per-lane walks over 64-byte nodes (node visits and leaf visits apart, rounds cut when few lanes still walk) -- both "
+                   "counted into the launch; trace_bvh_kernel when the tree holds triangles)",
                 5: "flat 4-wide BVH, regrouping schedule (trace_bvh_mesh_kernel: f32-only traversal step, exact f64 tests in the "
                    "shading phase; trace_bvh_regroup_kernel when the tree holds no triangles)",
                 6: "wavefront form (what AUTO runs for a pure mesh): level 0 = wf_generate_kernel, wf_trace_packet_kernel (f32 only, one "
