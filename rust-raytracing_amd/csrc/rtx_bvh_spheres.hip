@@ -140,6 +140,12 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
     float best_up = __builtin_inff();
     uint32_t qcnt = 0, nbox = 0, nleaf = 0, w_node = kNone, w_sp = 0;
     bool overflow = false, walked = false, midwalk = false;
+#ifdef RTX_SPH_PROFILE
+    unsigned long long rtx_prof = 0;
+#define RTX_PROF_PASS , rtx_prof
+#else
+#define RTX_PROF_PASS
+#endif
     const uint32_t cut_walkers = MODE == 1 ? 0u : sq.cut_walkers;       // stage 1 hands every lane a fresh ray each round: no cut there
 
     for (;;) {
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
                     if constexpr (Q3 == 2)            // node visits and leaf visits apart (the default)
                         sphere_walk_phased<STACK, SPILL>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
                                                          lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
-                                                         overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive, kSphLeafLanes);
+                                                         overflow, nbox, nleaf, cut_walkers, kSphCutDone, n_alive, kSphLeafLanes RTX_PROF_PASS);
                     else
                         sphere_walk_resumable<STACK, SPILL, true>(nodes, la.sphere_f32, la.sphere_prims, q, sr, w_node, w_sp, &lds_stack[0][0],
                                                                   lq, tid, spill, spill_entries, spill_stride, glane, best_up, qcnt,
@@ -251,6 +257,18 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
             }
         }
         // ---- phase 2, f64: exact tests of the candidates that can still be the winner, the shapes outside the tree, ray_hit
+#ifdef RTX_SPH_PROFILE
+        {   // lab build: 1 f64 phases (rounds), 2 the exact loop's wave iterations (8: its lane iterations = exact tests + skipped entries)
+            const unsigned long long fm = __ballot(alive && !midwalk);
+            if (RTX_SPH_PROFILE == 1 && fm != 0ull && (uint32_t)(__ffsll((long long)fm) - 1) == lane) rtx_prof += 1;
+            if (RTX_SPH_PROFILE == 2) {
+                uint32_t mx = alive && !midwalk && walked && !overflow ? qcnt : 0u;
+                for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, off, 64); mx = mx > o ? mx : o; }
+                if (lane == 0) rtx_prof += mx;
+            }
+            if (RTX_SPH_PROFILE == 8 && alive && !midwalk && walked && !overflow) rtx_prof += qcnt;
+        }
+#endif
         if (alive && !midwalk) {
             Hit h;
             hit_init(h);
@@ -305,6 +323,9 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
         }
     }
     if constexpr (MODE == 1) sph_queue_close(sq, lane, out_next, out_end);      // the unused rest of the wave's last reservation
+#ifdef RTX_SPH_PROFILE
+    if (MODE == 2) exact = rtx_prof;                             // lab build: stage 2 reports its profile count through exact_tests
+#endif
     // counters: segments, exact f64 shape tests, box tests + leaf filter tests (reported through filter_tests)
     unsigned long long filt = box_tests + leaf_filters;
 #pragma unroll

@@ -764,6 +764,11 @@ __device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf
     }
 }
 
+#ifdef RTX_SPH_PROFILE          // lab build (-DRTX_SPH_PROFILE=k): one per-lane count per build, summed and reported through exact_tests
+#define RTX_PROF_ARG , unsigned long long &rtx_prof
+#else
+#define RTX_PROF_ARG
+#endif
 // The resumable walk (below) in this form.  `node` is a link: type 0 = a node, 1..6 = a leaf; kNone = the walk has ended.
 // (Measured and dropped, LAB_NOTEBOOK R3.11: a lane that pops a leaf putting it aside in a register and going on with the next
 // entry instead of waiting for the wave's next leaf visit -- 54.8 against 54.6 ms, 1 % more box tests from the later best_up.)
@@ -774,11 +779,22 @@ __device__ __forceinline__ void sphere_walk_phased(const float4 *__restrict__ qn
                                                    uint32_t tid, uint32_t *__restrict__ spill, uint32_t spill_entries,
                                                    size_t spill_stride, size_t glane, float &best_up, uint32_t &qcnt, bool &overflow,
                                                    uint32_t &nbox, uint32_t &nleaf, uint32_t cut_walkers, uint32_t cut_done, uint32_t n_alive,
-                                                   uint32_t leaf_lanes)
+                                                   uint32_t leaf_lanes RTX_PROF_ARG)
 {
     while (node != kNone) {
         const bool at_leaf = (node >> 29) != 0u;
         const unsigned long long lm = __ballot(at_leaf), am = __ballot(true);
+#ifdef RTX_SPH_PROFILE
+        {   // lab build: 3 node-visit iterations, 4 lanes in them, 5 leaf-visit iterations, 6 lanes in them, 7 lanes in the loop
+            const bool leafv = (uint32_t)__popcll(lm) >= leaf_lanes || lm == am;
+            const bool leader = (uint32_t)(__ffsll((long long)am) - 1) == (tid & 63u);
+            if (RTX_SPH_PROFILE == 3 && !leafv && leader) rtx_prof += 1;
+            if (RTX_SPH_PROFILE == 4 && !leafv && !at_leaf) rtx_prof += 1;
+            if (RTX_SPH_PROFILE == 5 && leafv && leader) rtx_prof += 1;
+            if (RTX_SPH_PROFILE == 6 && leafv && at_leaf) rtx_prof += 1;
+            if (RTX_SPH_PROFILE == 7) rtx_prof += 1;
+        }
+#endif
         if ((uint32_t)__popcll(lm) >= leaf_lanes || lm == am) {
             if (at_leaf)
                 sphere_leaf_step<STACK, SPILL>(leaf_f32, leaf_prims, sr, node, sp, lds_stack, lds_q, tid, spill, spill_stride, glane,
