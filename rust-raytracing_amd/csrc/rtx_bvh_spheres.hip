@@ -1,18 +1,17 @@
-// rtx_bvh_spheres.hip -- trace_bvh_spheres_kernel: RTX_KERNEL_BVH for trees that hold spheres only (C2, C4).
+// rtx_bvh_spheres.hip -- RTX_KERNEL_BVH for trees that hold spheres only (C2, C4).
 //
-// Same rays, same tree, same exact tests and the same bits as trace_bvh_kernel<false, *> (rtx_bvh.hip); what differs is
-// the traversal loop, which holds no f64 value: it prunes with the conservative f32 distance bounds of
-// bvh_traverse_spheres (rtx_traverse.h) instead of the exact winner's distance, and the candidates that can still be the
-// winner get their exact f64 test (sphere.rs:19-30) once, after the walk.  What that buys on C2 (one MI355X, 64 spp):
-//   * 1381 -> 1471 Mrays/s at the same 4 waves per SIMD: no f64 code inside the loop (the old loop ran the exact tests
-//     every 4th step for the whole wave), 1.08 instead of 1.22 exact tests and 93.4 instead of 96.0 box tests per segment
-//     (the pruning bound no longer lags by up to 4 steps);
-//   * the traversal loop is free of scratch traffic (tools/isa_spills.py): what the allocator spills (31 VGPRs) is
-//     touched only between segments.
-// Measured and dropped: more waves per SIMD.  With the f64 state out of the loop the kernel also builds for 5 / 6 / 8
-// waves per SIMD (96 / 80 / 64 VGPRs, LDS stack 22 / 17 / 11 entries + the HBM column): 1420 / 1177 / 995 Mrays/s -- the
-// loop is VALU-issue bound (its min/max/cmp/cndmask mix issues at ~4 cycles per instruction, SQ counters in profiles/),
-// so extra waves add nothing and their spill reloads inside the loop (4 / 8 / 18 per step) cost.
+// Same rays, same tree, same exact tests and the same bits as trace_bvh_kernel<false, *> (rtx_bvh.hip); what differs is the
+// traversal, which holds no f64 value: it prunes with the conservative f32 distance bounds of rtx_traverse.h instead of the
+// exact winner's distance, and the candidates that can still be the winner get their exact f64 test (sphere.rs:19-30) once,
+// after the walk.  What is in this file, in the order a big launch runs it (history in profiles/LAB_NOTEBOOK.md):
+//   * trace_sph_packet_kernel      stage 1: the primary rays, ONE wave-uniform walk per 8x8 tile through the scalar cache
+//   * trace_bvh_spheres_kernel     stage 2 (MODE 2, from the survivors' queue) and small launches (MODE 0): per-lane walks over
+//                                  the 64-byte nodes, node visits and leaf visits apart (sphere_walk_phased), a wave leaving
+//                                  its round when few lanes still walk (the walk is resumable); MODE 1 = stage 1 per lane (A/B)
+//   * trace_sph_pool_kernel, trace_sph_pair_kernel, sph_sort_*   experiments behind RtxConfig.tuning bits (slower or on par)
+// The traversal loops are free of scratch traffic (tools/isa_spills.py): what the allocator spills (the f64 path state) is touched
+// only between walks.  4 workgroups per CU: the loops are VALU-issue bound, more waves only add spill reloads inside them
+// (5 / 6 / 8 per SIMD measured in round 1), 3 without any spill are 3 % slower (round 3).
 #include "rtx_launch.h"
 #include "rtx_traverse.h"
 
