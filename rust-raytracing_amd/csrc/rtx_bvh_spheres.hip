@@ -483,6 +483,56 @@ __device__ __forceinline__ void sph_packet_walk(const PkConst4 cnodes, const PkC
         // interior children any lane still enters, nearest first by the first entering lane's distance (wave-uniform
         // integer keys -- the bits of a non-negative float order like the float; a far origin's slack can make a bound
         // negative: as a signed integer it still sorts in front --: scalar code); the farther ones are pushed
+#ifndef RTX_SPK_FAST1
+#define RTX_SPK_FAST1 2
+#endif
+#if RTX_SPK_FAST1
+        // no or one interior child entered (the common case below the top levels): nothing to order, nothing to push -- the ordering
+        // below is ~65 scalar instructions, and the packet walk is bound by the CU's scalar pipe
+        {
+            uint32_t ib = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ib |= (cnt[c] == 0u && hm[c] != 0ull) ? 1u << c : 0u;
+#if defined(RTX_SPK_LAB) && RTX_SPK_LAB >= 10         // lab build: visits by the number of interior children entered (through nleaf of lane 0)
+            if (lane == 0 && (uint32_t)__builtin_popcount(ib) == (uint32_t)(RTX_SPK_LAB - 10)) nleaf += 1000000u;
+#endif
+            if ((ib & (ib - 1u)) == 0u) {
+                node = ib == 0u ? kNone : (ib == 1u ? lnk[0] : (ib == 2u ? lnk[1] : (ib == 4u ? lnk[2] : lnk[3])));
+                if (node == kNone && sp != 0u) {
+                    sp -= 1;
+                    node = (uint32_t)__builtin_amdgcn_readlane(stk, (int)sp);
+                }
+                continue;
+            }
+#if RTX_SPK_FAST1 >= 2
+            // two (20 % of the visits; none or one: 73 %): one comparison of the two first-entering lanes' distances, one push --
+            // the same order as the network below gives (the later child goes first only when strictly nearer)
+            if (__builtin_popcount(ib) == 2) {
+                uint32_t far_link = 0;
+#define RTX_SPK_PAIR(A, B)                                                                                                        \
+                {                                                                                                                   \
+                    const int ka = (int)__builtin_amdgcn_readlane(__float_as_uint(tc[A]), (int)__builtin_ctzll(hm[A]));            \
+                    const int kb = (int)__builtin_amdgcn_readlane(__float_as_uint(tc[B]), (int)__builtin_ctzll(hm[B]));            \
+                    const bool sw = kb < ka;                                                                                        \
+                    node = sw ? lnk[B] : lnk[A];                                                                                    \
+                    far_link = sw ? lnk[A] : lnk[B];                                                                                \
+                }
+                switch (ib) {
+                    case 3u: RTX_SPK_PAIR(0, 1) break;
+                    case 5u: RTX_SPK_PAIR(0, 2) break;
+                    case 9u: RTX_SPK_PAIR(0, 3) break;
+                    case 6u: RTX_SPK_PAIR(1, 2) break;
+                    case 10u: RTX_SPK_PAIR(1, 3) break;
+                    default: RTX_SPK_PAIR(2, 3) break;
+                }
+#undef RTX_SPK_PAIR
+                stk = rtx_writelane((int)far_link, (int)sp, stk);
+                sp += 1u;
+                continue;
+            }
+#endif
+        }
+#endif
         int key[4];
         uint32_t kl[4];
         constexpr int kFar = 0x7F800000;
@@ -572,7 +622,11 @@ __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kerne
                 walked = true;
             }
         }
+#if defined(RTX_SPK_LAB) && RTX_SPK_LAB == 1            // lab timing build: no walk (wrong images)
+        const unsigned long long wm = 0ull;
+#else
         const unsigned long long wm = __ballot(walked);
+#endif
         if (wm != 0ull) {
             const uint32_t my_sgn = (q.ix < 0.0f ? 1u : 0u) | (q.iy < 0.0f ? 2u : 0u) | (q.iz < 0.0f ? 4u : 0u);
             const uint32_t sgn = __builtin_amdgcn_readlane(my_sgn, (int)(__ffsll((long long)wm) - 1));
@@ -594,7 +648,11 @@ __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kerne
         // ---- phase 2, f64, all lanes together: the exact tests of the candidates that can still be the winner, the shapes
         //      outside the tree, ray_hit
         uint32_t first_id = 0;
+#if defined(RTX_SPK_LAB) && RTX_SPK_LAB == 2            // lab timing build: no f64 phase after the walk (wrong images)
+        if (alive && best_up == 12345.0f) {
+#else
         if (alive) {
+#endif
             Hit h;
             hit_init(h);
             ++segs;

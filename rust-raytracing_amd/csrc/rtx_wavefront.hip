@@ -405,7 +405,25 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
                 }
             }
             // interior children any lane entered, nearest first (wave-uniform integer keys: scalar code); the farther ones go
-            // to the wave's stack
+            // to the wave's stack.  None or one entered (most visits below the top levels): nothing to order, nothing to push --
+            // the network and the three pushes are ~45 scalar instructions, and this walk is bound by the CU's scalar pipe
+#ifndef RTX_PK_FAST1
+#define RTX_PK_FAST1 1
+#endif
+#if RTX_PK_FAST1
+            {
+                const uint32_t vb = (key[0] != 0x7F800000u ? 1u : 0u) | (key[1] != 0x7F800000u ? 2u : 0u) |
+                                    (key[2] != 0x7F800000u ? 4u : 0u) | (key[3] != 0x7F800000u ? 8u : 0u);
+                if ((vb & (vb - 1u)) == 0u) {
+                    node = vb == 0u ? kNone : (vb == 1u ? kl[0] : (vb == 2u ? kl[1] : (vb == 4u ? kl[2] : kl[3])));
+                    if (node == kNone && sp != 0u) {
+                        sp -= 1;
+                        node = lane_stack ? (uint32_t)__builtin_amdgcn_readlane(stk_v, (int)sp) : __builtin_amdgcn_readfirstlane(stk[sp]);
+                    }
+                    continue;
+                }
+            }
+#endif
 #define RTX_CSWAP(i, j) { if (key[j] < key[i]) { uint32_t tk = key[i]; key[i] = key[j]; key[j] = tk; uint32_t tl = kl[i]; kl[i] = kl[j]; kl[j] = tl; } }
             RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP

@@ -43,9 +43,12 @@ for spec in specs:
         ts.append(time.perf_counter() - t0)
     out[spec] = band[:part.n_rows].clone()
     rays = part.n_rows * w * spp
-    print("%-8s (ran %d): %.2f ms  trace %.2f ms  %.1f Mrays/s  seg %d exact/seg %.3f box/seg %.1f launches %d" % (
-        spec, st.kernel, min(ts) * 1e3, st.trace_ms, rays / min(ts) / 1e6, st.segments, st.exact_tests / max(st.segments, 1),
+    print("%-8s (ran %d): %.2f ms  trace %.2f ms%s  %.1f Mrays/s  seg %d exact/seg %.3f box/seg %.1f launches %d" % (
+        spec, st.kernel, min(ts) * 1e3, st.trace_ms, "  (stage 1 %.2f ms)" % st.stage1_ms if getattr(st, "stage1_ms", 0.0) else "",
+        rays / min(ts) / 1e6, st.segments, st.exact_tests / max(st.segments, 1),
         st.box_tests / max(st.segments, 1), st.trace_launches), flush=True)
+    if os.environ.get("LAB"):
+        print("    filter_tests - box_tests = %d" % (st.filter_tests - st.box_tests), flush=True)
     hnd.close()
 ref = out[specs[0]].view(torch.int64)
 same = all(torch.equal(ref, out[s].view(torch.int64)) for s in specs[1:])
