@@ -331,6 +331,38 @@ def roofline_of(acc, cfg, counters, source, per_kernel=None):
     return out
 
 
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def summary_of(line):
+    """The figures a reader wants first, once more and compactly, as the LAST key of the line (every value is a copy of one above)."""
+    def roof(r):
+        return {"frac_useful": _r(r.get("frac")), "issued": _r((r.get("issued") or {}).get("frac")), "lanes": _r(r.get("lane_utilisation"), 3),
+                "valu_busy": _r(r.get("valu_busy"), 3), "hbm_frac": _r(r.get("hbm_frac"), 3),
+                "traffic_GB": _r(r["traffic"] / 1e9, 1) if r.get("traffic") else None}
+    r = line["roofline"]
+    out = {"value_Mrays_s": _r(line["value"], 1), "ms_per_step": _r(line["ms_per_step"], 2), "n_gpus": line["n_gpus"], **roof(r),
+           "stages": [{"stage": s_["stage"][:7], "ms": _r(s_["ms"], 2), "frac_useful": _r(s_["frac"]), "issued": _r(s_.get("issued_frac")),
+                       "lanes": _r(s_.get("lane_utilisation"), 3), "valu_busy": _r(s_.get("valu_busy"), 3), "salu_busy": _r(s_.get("salu_busy"), 3),
+                       "traffic_GB": _r(s_["traffic"] / 1e9, 1) if s_.get("traffic") else None} for s_ in r.get("stages", [])]}
+    if "other_configs" in line:
+        out["other_configs"] = [{"config": o["config"], "frame": "band" if "band" in o["workload"] else "full", "Mrays_s": _r(o["value"], 1),
+                                 "ms": _r(o["ms_per_step"], 2), **roof(o["roofline"]),
+                                 "band_over_full": _r(o.get("band_rate_over_full_frame_rate"), 3),
+                                 "kernels_ms": {k["kernel"][:28]: _r(k["avg_ms_per_launch"], 2) for k in o["roofline"].get("kernels", [])}}
+                                for o in line["other_configs"]]
+    if "lds_sweep" in line:
+        out["lds_sweep_Mrays_s"] = _r(line["lds_sweep"]["value"], 1)
+    if "partition_balance" in line:
+        out["partition_8_max_over_mean"] = _r(line["partition_balance"]["max_over_mean"], 4)
+    if "cpu_baseline" in line:
+        cb = line["cpu_baseline"]
+        out["cpu_baseline"] = {"Mrays_s": _r(cb["value"], 5), "cores": cb["cores"], "kind": cb["kind"],
+                               "like_for_like_linear_scan_x": _r(line["speedup_vs_cpu"].get("like_for_like_linear_scan"), 0)}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # rocprofv3 counters, collected in this run
 # ---------------------------------------------------------------------------------------------------------------------
@@ -741,6 +773,7 @@ def main():
                                               "sweep (which scans the list as the reference does) / the same CPU rate"}
         if log:
             line["log"] = log
+        line["summary"] = summary_of(line)          # last: the line is ~50 KB, a record that keeps only the tail of stdout still shows this
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1259,6 +1259,8 @@ def test_bench_line_contract(gpu):
     assert d["speedup_vs_cpu"]["like_for_like_linear_scan"] > 10          # the LDS sweep scans the list as the CPU does
     assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5", "C5"]
     assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, False, True]
+    assert list(d)[-1] == "summary" and abs(d["summary"]["value_Mrays_s"] - d["value"]) < 0.06 and len(d["summary"]["other_configs"]) == 5
+    assert len(json.dumps(d["summary"])) < 4096                      # the tail of stdout a record keeps still shows it
     bal = d["partition_balance"]
     assert len(bal["segments_per_band"]) == 8 and 1.0 <= bal["max_over_mean"] < 1.1        # blocks of 8 rows round-robin balance the frame
     assert d["other_configs"][1]["band_rate_over_full_frame_rate"] > 0
