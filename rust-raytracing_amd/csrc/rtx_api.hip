@@ -841,6 +841,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
     rv.width = width; rv.height = height;
     rv.row_begin = row_begin; rv.row_stride = row_stride; rv.n_rows = n_rows; rv.row_block = row_block;
     rv.npix = npix;
+    rv.div_width = make_fastdiv(width); rv.div_row_block = make_fastdiv(row_block); rv.div_npix = make_fastdiv(npix);
+    rv.div_tiles_x = make_fastdiv(tiles_x); rv.div_per_sample = make_fastdiv(per_sample);
     rv.sin_x = h->tables; rv.cos_x = h->tables + width;
     rv.sin_y = h->tables + 2 * (size_t)width; rv.cos_y = rv.sin_y + n_rows;
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                         ridx = src.ridx[(size_t)my * src.ridx_stride];
                         if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                         else ray_index_to_pixel(rv, ridx, pl, smp);
-                        const uint32_t k = pl / rv.width, x = pl - k * rv.width;
+                        const uint32_t k = fastdiv(pl, rv.div_width), x = pl - k * rv.width;
                         const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                         r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                         r.bounce = 1u;

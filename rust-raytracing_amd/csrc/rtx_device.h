@@ -59,6 +59,34 @@ struct SceneView {
 };
 
 // Which pixels/samples one launch covers.
+// n / d for a divisor that is fixed for the launch: q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n) -- exact for every 32-bit n
+// (Granlund & Montgomery's round-up multiplier; l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, s1 = min(l, 1), s2 = max(l - 1, 0)).
+// Five integer instructions instead of the ~30 of an emulated 32-bit division (~150 for the 64-bit form): a ray's index -> pixel
+// arithmetic has four of them, once per primary ray and once per refill of the queue-fed kernels.
+struct FastDiv { uint32_t m, s1, s2, d; };
+
+inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f;
+    f.d = d ? d : 1u;
+    uint32_t l = 0;
+    while (l < 32u && (1ull << l) < (unsigned long long)f.d) ++l;
+    f.m = (uint32_t)((((1ull << l) - (unsigned long long)f.d) << 32) / (unsigned long long)f.d + 1ull);
+    f.s1 = l < 1u ? l : 1u;
+    f.s2 = l > 1u ? l - 1u : 0u;
+    return f;
+}
+
+RTX_HD uint32_t fastdiv(uint32_t n, const FastDiv &f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(f.m, n);
+#else
+    const uint32_t t = (uint32_t)(((unsigned long long)f.m * (unsigned long long)n) >> 32);
+#endif
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct RowsView {
     uint32_t width, height;
     uint32_t row_begin, row_stride, n_rows;       // local row k is image row image_row(rv, k)
@@ -74,6 +102,7 @@ struct RowsView {
     // host-libm trig tables (scene.rs:214-220): sin/cos(fov*(x/w-0.5)) per column,
     // sin/cos(vfov*(y/h-0.5)) per LOCAL row
     const double *sin_x, *cos_x, *sin_y, *cos_y;
+    FastDiv div_width, div_row_block, div_npix, div_tiles_x, div_per_sample;    // per_sample = tiles_x * tiles_y * 64 (the host keeps n_rays < 2^32)
 };
 
 // Local row k of a band -> image row.  The band is made of blocks of row_block consecutive image rows, row_stride rows
@@ -82,7 +111,7 @@ struct RowsView {
 // neighbouring pixels whatever the number of bands -- with single interleaved rows it is 8 columns x 8n image rows.
 RTX_HD uint32_t image_row(const RowsView &rv, uint32_t k)
 {
-    const uint32_t b = k / rv.row_block;
+    const uint32_t b = fastdiv(k, rv.div_row_block);
     return rv.row_begin + b * rv.row_stride + (k - b * rv.row_block);
 }
 
@@ -123,20 +152,18 @@ __device__ __forceinline__ void hit_consider(Hit &h, double t, uint32_t id, uint
 // are 64 neighbouring pixels of one sample (coalesced sample-plane writes).
 __device__ __forceinline__ void ray_index_to_pixel(const RowsView &rv, uint64_t i, uint32_t &pl, uint32_t &s_local)
 {
-    s_local = (uint32_t)(i / rv.npix);
-    pl = (uint32_t)(i - (uint64_t)s_local * rv.npix);
+    s_local = fastdiv((uint32_t)i, rv.div_npix);              // (i < n_rays < 2^32)
+    pl = (uint32_t)i - s_local * rv.npix;
 }
 
 // The same over 8x8 pixel tiles: 64 consecutive indices = one tile of one sample (more coherent primary rays than a
 // 64x1 strip: shared nodes, similar traversal lengths).  Returns false for the padding of partial tiles.
 __device__ __forceinline__ bool ray_index_to_pixel_tiled(const RowsView &rv, uint64_t i, uint32_t &pl, uint32_t &s_local)
 {
-    const uint32_t tiles_y = (rv.n_rows + 7u) >> 3;
-    const uint64_t per_sample = (uint64_t)rv.tiles_x * tiles_y * 64u;
-    s_local = (uint32_t)(i / per_sample);
-    const uint32_t r = (uint32_t)(i - (uint64_t)s_local * per_sample);
+    s_local = fastdiv((uint32_t)i, rv.div_per_sample);        // (i < n_rays < 2^32)
+    const uint32_t r = (uint32_t)i - s_local * rv.div_per_sample.d;
     const uint32_t t = r >> 6, j = r & 63u;
-    const uint32_t ty = t / rv.tiles_x, tx = t - ty * rv.tiles_x;
+    const uint32_t ty = fastdiv(t, rv.div_tiles_x), tx = t - ty * rv.tiles_x;
     const uint32_t x = tx * 8u + (j & 7u), k = ty * 8u + (j >> 3);
     pl = k * rv.width + x;
     return x < rv.width && k < rv.n_rows;
@@ -158,7 +185,7 @@ __device__ __forceinline__ void store_sample(double *__restrict__ samples, const
 __device__ __forceinline__ void gen_primary(const SceneView &sv, const RowsView &rv, uint32_t pl, uint32_t sample,
                                             RayState &r)
 {
-    uint32_t k = pl / rv.width;                    // local row
+    uint32_t k = fastdiv(pl, rv.div_width);        // local row
     uint32_t x = pl - k * rv.width;
     uint32_t y = image_row(rv, k);
     uint64_t pix = (uint64_t)y * rv.width + x;     // index in the FULL image keys the RNG

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_EU) void trace_mixed_kernel(cons
             bool done = true;
             if (h.id != kInvalid) {                                            // scene.rs:233-236
                 r.light = mk(st[9 * n_slots], st[10 * n_slots], st[11 * n_slots]);
-                const uint32_t k = pl / rv.width;
+                const uint32_t k = fastdiv(pl, rv.div_width);
                 const uint32_t x = pl - k * rv.width;
                 const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                 r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);

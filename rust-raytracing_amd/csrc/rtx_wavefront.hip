@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(co
                 uint32_t pl = 0, smp = 0;
                 if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
                 else ray_index_to_pixel(rv, ridx, pl, smp);
-                const uint32_t k = pl / rv.width, x = pl - k * rv.width;
+                const uint32_t k = fastdiv(pl, rv.div_width), x = pl - k * rv.width;
                 const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
                 r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
                 r.draw = 6u + 2u * level;
