@@ -31,7 +31,7 @@ out = {}
 for spec in specs:
     k, _, t = spec.partition(":")
     k, t = int(k), int(t, 0) if t else 0
-    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k, tuning=t, max_bounces=int(os.environ.get("MAXB", 10))), rtx.Camera(*scenes.CAMERA), objs).upload(0)
+    hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k, tuning=t, max_bounces=int(os.environ.get("MAXB", 10)), non_focal_offset=float(os.environ.get("NFO", 0.1))), rtx.Camera(*scenes.CAMERA), objs).upload(0)
     band = part.alloc_band(w, dev)
     part.render(hnd, w, band)
     torch.cuda.synchronize()
