@@ -16,12 +16,17 @@ CAMS = [((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), math.pi / 2),            # the benchm
         ((60.0, -80.0, 0.0), (0.0, 1.0, 0.0), 1.0)]                 # looking along +y
 
 
+SEED_BASE = int(os.environ.get("SEED_BASE", 1000))     # SPP / SEED_BASE in the environment: another sample of the same scenes
+SPP = int(os.environ.get("SPP", 1))
+
+
 def run(name, objs, w, h, spp, kernels):
+    spp = SPP
     total = 0
     for ci, cam in enumerate(CAMS):
         out = {}
         for kern in [rtx.RTX_KERNEL_EXACT] + kernels:
-            hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=1000 + ci, kernel=kern), rtx.Camera(*cam), objs).upload(0)
+            hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=SEED_BASE + ci, kernel=kern), rtx.Camera(*cam), objs).upload(0)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
             out[kern] = (buf.cpu().numpy(), st.segments)
