@@ -666,7 +666,9 @@ __device__ __forceinline__ void sphere_node_step_q3(const float4 *__restrict__ q
         const float tf = fminf(fminf(x1, y1), z1);
         const float tn_lo = __builtin_fmaf(tn, 1.0f - 4.76837158e-7f, -e);
         const float tf_hi = __builtin_fmaf(tf, 1.0f + 4.76837158e-7f, e);
-        const float key = (tn_lo <= tf_hi && tn_lo <= best_up && lk[c] < 0xE0000000u) ? tn_lo : __builtin_inff();   // (type 7: an empty slot)
+        // (one compare against the smaller of the two limits; type 7 is an empty slot: one select for both conditions)
+        const bool enter = (tn_lo <= fminf(tf_hi, best_up)) & (lk[c] < 0xE0000000u);
+        const float key = enter ? tn_lo : __builtin_inff();
         kd[c] = __hiloint2double((int)__float_as_uint(key), (int)lk[c]);
     }
     nbox += 4;
