@@ -115,6 +115,27 @@ def _rust_repr_c_layouts(path):
     return out
 
 
+def test_enum_constants_match_the_header(rtx, tmp_path):
+    """Every RTX_KERNEL_* / RTX_TUNE_* / RTX_ERR_* / RTX_OK enumerator of include/rtx_hip.h, as gcc evaluates it, against the
+    Python mirror (rust-raytracing_amd/abi.py): an A/B bit that drifted would silently select another kernel in the tests."""
+    import re
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "rtx_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(RTX_(?:KERNEL|TUNE|ERR)_[A-Z0-9_]+|RTX_OK)\b\s*=", hdr)))
+    assert len(names) > 25
+    src = tmp_path / "enums.c"
+    src.write_text('#include <stdio.h>\n#include "rtx_hip.h"\nint main(void){\n' +
+                   "".join('printf("%s %%lld\\n", (long long)%s);\n' % (n, n) for n in names) + "return 0;}\n")
+    exe = tmp_path / "enums"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    from rust_raytracing_amd import abi
+    missing = [n for n in names if not hasattr(abi, n)]
+    assert not missing, missing
+    for n in names:
+        assert int(vals[n]) == int(getattr(abi, n)), n
+
+
 def test_rust_shim_matches_the_header(tmp_path):
     """rust/src/raytracing/hip.rs cannot be compiled here (no rustc): its #[repr(C)] structs are parsed and laid out by
     the C rules, and must have the header's field names, order, offsets and sizes; its extern "C" block must declare
