@@ -15,8 +15,13 @@ value = 1920*1080*64 * K / (max-over-ranks time of the K steps).  --weak multipl
 (fixed rays per GPU; labelled as such, not the metric).  --config C3|C4|C5 benches another BASELINE.json config as the
 primary workload (C4 = 3840x2160 at 1024 spp is the one named for 8 GPUs).
 
-At N = 1 with the default config the line also carries
-  other_configs   C3 full frame + the band rank 0 of 8 owns of C3, C4 and C5, at a stated reduced spp: rate + roofline each
+stdout carries ONE compact JSON line (< 2000 characters: the contract's keys, `roofline` and `cpu_baseline` as objects of a
+few scalars, the other legs as rows of numbers); the FULL record -- everything described below -- goes to --detail-out
+(default gpurun_out/bench_detail_n<N>.json; the line names it in `detail`).
+
+At N = 1 with the default config the record also carries
+  other_configs   C3 full frame (at its named 64 spp) + the band rank 0 of 8 owns of C3, C4 and C5 + the C5 full frame, at a
+                  stated spp: rate + roofline each
   lds_sweep       the LDS-staged f32-filter sweep BASELINE.json's configs[1] describes, same frame, same bits
   cpu_baseline    the CPU oracle on this host's cores, on a sub-sample of the SAME 1920x1080 view
 
@@ -90,6 +95,9 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                    "then trace_bvh_mesh_kernel continues from the level-1 queue (or, for an L2-resident tree with >= 2^24 rays per "
                    "launch, wf_trace_kernel + wf_shade_kernel per bounce level); the roofline object covers the whole sequence of "
                    "one launch, wf_trace_packet_kernel is ~55 % of it"}
+KERNEL_SHORT = {1: "trace_exact_kernel", 2: "trace_mixed_kernel (LDS sweep)", 3: "trace_mixed_kernel+verify",
+                4: "BVH: trace_sph_packet_kernel + trace_bvh_spheres_kernel", 5: "trace_bvh_mesh_kernel (regroup)",
+                6: "wavefront: wf_trace_packet_kernel + trace_bvh_mesh_kernel"}
 # substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
 KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
                  4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel", "trace_sph_packet_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel", "trace_bvh_spheres_pool_kernel"),
@@ -121,7 +129,10 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip C3 / C4 band / C5 band at N = 1")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect rocprofv3 counters in this run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of each cpu_baseline mode")
-    ap.add_argument("--other-spp", default="C3=8,C3band=64,C4=64,C5=1,C5band=4", help="rays per pixel of the other_configs legs")
+    ap.add_argument("--other-spp", default="C3=64,C3band=64,C4=64,C5=1,C5band=4", help="rays per pixel of the other_configs legs")
+    ap.add_argument("--detail-out", default=None,
+                    help="file that receives the FULL record (per-kernel counters, every leg's roofline object, the log); default "
+                         "gpurun_out/bench_detail_n<N>.json under the repo root.  stdout carries ONE compact line (< 2000 characters)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the gather goes through gloo on host "
                          "copies (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
@@ -258,7 +269,7 @@ def roofline_of(acc, cfg, counters, source, per_kernel=None):
     avg_ms = acc.trace_ms / max(acc.launches, 1)                  # average duration of ONE launch (hipEvents, launch stream)
     alg = algorithmic(acc, cfg)
     out = {"bound": "valu", "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "kernel": KERNEL_NAMES.get(acc.kernel, str(acc.kernel)),
-           "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+           "kernel_short": KERNEL_SHORT.get(acc.kernel, str(acc.kernel)), "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
            "achieved": alg["Tlane_ops_per_s"], "frac": alg["frac_of_valu_peak"],
            "frac_source": "useful lane-instructions (the tests the kernel counted in this run x LANE_OPS) / launch time / peak",
            "issued": None, "lane_utilisation": None, "valu_busy": None, "valu_cycles_per_instruction": None, "effective_clock_ghz": None,
@@ -335,32 +346,92 @@ def _r(x, n=4):
     return round(x, n) if isinstance(x, float) else x
 
 
-def summary_of(line):
-    """The figures a reader wants first, once more and compactly, as the LAST key of the line (every value is a copy of one above)."""
-    def roof(r):
-        return {"frac_useful": _r(r.get("frac")), "issued": _r((r.get("issued") or {}).get("frac")), "lanes": _r(r.get("lane_utilisation"), 3),
-                "valu_busy": _r(r.get("valu_busy"), 3), "hbm_frac": _r(r.get("hbm_frac"), 3),
-                "traffic_GB": _r(r["traffic"] / 1e9, 1) if r.get("traffic") else None}
-    r = line["roofline"]
-    out = {"value_Mrays_s": _r(line["value"], 1), "ms_per_step": _r(line["ms_per_step"], 2), "n_gpus": line["n_gpus"], **roof(r),
-           "stages": [{"stage": s_["stage"][:7], "ms": _r(s_["ms"], 2), "frac_useful": _r(s_["frac"]), "issued": _r(s_.get("issued_frac")),
-                       "lanes": _r(s_.get("lane_utilisation"), 3), "valu_busy": _r(s_.get("valu_busy"), 3), "salu_busy": _r(s_.get("salu_busy"), 3),
-                       "traffic_GB": _r(s_["traffic"] / 1e9, 1) if s_.get("traffic") else None} for s_ in r.get("stages", [])]}
-    if "other_configs" in line:
-        out["other_configs"] = [{"config": o["config"], "frame": "band" if "band" in o["workload"] else "full", "Mrays_s": _r(o["value"], 1),
-                                 "ms": _r(o["ms_per_step"], 2), **roof(o["roofline"]),
-                                 "band_over_full": _r(o.get("band_rate_over_full_frame_rate"), 3),
-                                 "kernels_ms": {k["kernel"][:28]: _r(k["avg_ms_per_launch"], 2) for k in o["roofline"].get("kernels", [])}}
-                                for o in line["other_configs"]]
-    if "lds_sweep" in line:
-        out["lds_sweep_Mrays_s"] = _r(line["lds_sweep"]["value"], 1)
-    if "partition_balance" in line:
-        out["partition_8_max_over_mean"] = _r(line["partition_balance"]["max_over_mean"], 4)
-    if "cpu_baseline" in line:
-        cb = line["cpu_baseline"]
-        out["cpu_baseline"] = {"Mrays_s": _r(cb["value"], 5), "cores": cb["cores"], "kind": cb["kind"],
-                               "like_for_like_linear_scan_x": _r(line["speedup_vs_cpu"].get("like_for_like_linear_scan"), 0)}
-    return out
+def _sig(x, n=4):
+    """x rounded to n significant digits (None and non-floats pass through): the compact line is read by people and parsers."""
+    if not isinstance(x, float) or x != x or x in (float("inf"), float("-inf")):
+        return None if isinstance(x, float) else x
+    return float("%.*g" % (n, x))
+
+
+COMPACT_LIMIT = 2000          # characters of the ONE stdout line (records keep only a tail of stdout; r03's 53 KB line went unparsed)
+OTHER_COLS = ["Mrays_s", "ms", "spp", "frac", "issued", "lanes", "GB", "band_over_full"]
+
+
+def compact_line(full, detail_path):
+    """The contract line: every key the driver's parser reads, `roofline` and `cpu_baseline` as objects of a few scalars, the
+    other legs as rows of numbers (columns named once).  Every value is a rounded copy of one in the full record (`detail`)."""
+    r = full["roofline"]
+    roof = {"bound": r["bound"], "achieved": _sig(r["achieved"]), "peak": _sig(r["peak"]), "unit": r["unit"], "frac": _sig(r["frac"]),
+            "traffic": _sig(r["traffic"]) if r.get("traffic") else None,
+            "issued_frac": _sig((r.get("issued") or {}).get("frac")), "lane_utilisation": _sig(r.get("lane_utilisation"), 3),
+            "valu_busy": _sig(r.get("valu_busy"), 3), "hbm_frac": _sig(r.get("hbm_frac"), 3),
+            "avg_launch_ms": _sig(r["avg_launch_ms"]), "kernel": r.get("kernel_short"),
+            "counters": "live" if "of this run" in (r.get("counters_source") or "") else
+                        ("stored" if "pmc_counters.json (" in (r.get("counters_source") or "") else None)}
+    if r.get("stages"):
+        roof["stages"] = [{"k": (s_.get("kernel") or s_["stage"])[:24], "ms": _sig(s_["ms"]), "frac": _sig(s_["frac"], 3),
+                           "issued": _sig(s_.get("issued_frac"), 3), "lanes": _sig(s_.get("lane_utilisation"), 3),
+                           "valu_busy": _sig(s_.get("valu_busy"), 3), "salu_busy": _sig(s_.get("salu_busy"), 3),
+                           "GB": _sig(s_["traffic"] / 1e9, 3) if s_.get("traffic") else None} for s_ in r["stages"]]
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _sig(full["value"], 6), _sig(full["ms_per_step"], 5)
+    if "rehearsal" in full:
+        out["rehearsal"] = True
+    c = full["config"]
+    out["config"] = {"workload": c["workload_short"], "width": c["width"], "height": c["height"], "rays_per_pixel": c["rays_per_pixel"],
+                     "n_objects": c["n_objects"], "partition": c["partition_short"]}
+    out["segments_per_primary_ray"] = _sig(full["segments_per_primary_ray"], 5)
+    out["image_mean"] = _sig(full["image_mean"], 9)
+    out["roofline"] = roof
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb["sample_short"], "threads_started": cb["threads_started"],
+                               "single_thread_Mrays_s": _sig(cb["single_thread_Mrays_s"]), "faithful_Mrays_s": _sig(cb["faithful_Mrays_s"])}
+        out["gpu_over_cpu"] = {"tree_walk": _sig(full["speedup_vs_cpu"].get("primary_rays"), 3),
+                               "lds_sweep_like_for_like": _sig(full["speedup_vs_cpu"].get("like_for_like_linear_scan"), 3)}
+    if "lds_sweep" in full:
+        out["lds_sweep_Mrays_s"] = _sig(full["lds_sweep"]["value"])
+    if "other_configs" in full:
+        out["other_cols"] = OTHER_COLS
+        rows = {}
+        for o in full["other_configs"]:
+            ro = o["roofline"]
+            rows[o["leg"]] = [_sig(o["value"]), _sig(o["ms_per_step"]), o["rays_per_pixel"], _sig(ro.get("frac"), 3),
+                              _sig((ro.get("issued") or {}).get("frac"), 3), _sig(ro.get("lane_utilisation"), 3),
+                              _sig(ro["traffic"] / 1e9, 3) if ro.get("traffic") else None, _sig(o.get("band_rate_over_full_frame_rate"), 3)]
+        out["other_configs"] = rows
+    if "partition_balance" in full:
+        out["partition_8_max_over_mean"] = _sig(full["partition_balance"]["max_over_mean"], 4)
+    if "load_imbalance_max_over_mean" in full:
+        out["load_imbalance_max_over_mean"] = _sig(full["load_imbalance_max_over_mean"], 4)
+    out["detail"] = detail_path
+    text = json.dumps(out, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:                                  # never let the line outgrow what a record keeps: drop the extras first
+        for k in ("image_mean", "segments_per_primary_ray", "gpu_over_cpu", "partition_8_max_over_mean", "lds_sweep_Mrays_s", "other_cols",
+                  "other_configs"):
+            out.pop(k, None)
+            text = json.dumps(out, separators=(",", ":"))
+            if len(text) < COMPACT_LIMIT:
+                break
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def write_detail(full, path, n_gpus):
+    """The full record goes to a file; returns the path written (relative to the repo root when inside it) or None."""
+    cands = [path] if path else [os.path.join(ROOT, "gpurun_out", "bench_detail_n%d.json" % n_gpus),
+                                 os.path.join(tempfile.gettempdir(), "rtx_bench_detail_n%d.json" % n_gpus)]
+    for p in cands:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(p)), exist_ok=True)
+            with open(p, "w") as fh:
+                json.dump(full, fh, indent=1)
+            return os.path.relpath(p, ROOT) if os.path.abspath(p).startswith(ROOT + os.sep) else p
+        except OSError:
+            continue
+    return None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -565,6 +636,8 @@ def cpu_baseline(seconds):
                   "segments per ray) through the f64 C restatement of the reference CPU path (the Rust crate cannot be built "
                   "here), clean mode: %d threads, no locks; linear scan over the 10^4 spheres per segment as the reference does "
                   "(scene.rs:243-251)" % (clean[5], clean[3], clean[4] / max(clean[3], 1), cores),
+        "sample_short": "every %dth row+column of the C2 1080p frame (%d px, 1 spp), C port of the CPU path, %d threads; ~%.0f s CPU" % (
+            clean[5], clean[3], cores, single[2] + clean[2] + fdt),
         "Msegments_s": clean[1], "segments_per_primary_ray": clean[4] / max(clean[3], 1), "seconds": single[2] + clean[2] + fdt,
         "clean_Mrays_s": clean[0], "faithful_Mrays_s": faithful[0], "faithful_Msegments_s": faithful[1],
         "faithful_sample": "%d whole rows of the same frame (%d rays), one OS thread per row + a mutex per object "
@@ -713,7 +786,7 @@ def main():
             leg = "%s:%d:%s:0" % (name, s, "band" if band else "full")
             cnt, pk, src = counters_for(leg, KERNEL_SYMBOL.get(a.kernel, ("trace_",)), live_pmc, log, a.launches / max(a.n, 1))
             rec = {
-                "config": name, "workload": "%s, %s at %d spp (the config names %d spp; Mrays/s is a rate)" % (
+                "config": name, "leg": name + ("band" if band else ""), "rays_per_pixel": s, "workload": "%s, %s at %d spp (the config names %d spp; Mrays/s is a rate)" % (
                     oc["name"], "the band rank 0 of 8 owns (%d rows in blocks of %d)" % (part.n_rows, part.block) if band else "full frame", s, oc["spp"]),
                 "value": rays / e / 1e6, "unit": "Mrays/s", "ms_per_step": e / 2 * 1e3,
                 "Msegments_per_s": a.segments / e / 1e6, "segments_per_primary_ray": a.segments / rays,
@@ -743,6 +816,8 @@ def main():
             **({"rehearsal": "all ranks on cuda:0, gloo gather through host memory: not a measurement"} if rehearse else {}),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s, %d rays per pixel in total, max_bounces 10, render seed 42" % (args.config, cfg["name"], spp),
+                       "workload_short": "%s: %s, %d spp" % (args.config, cfg["name"], spp),
+                       "partition_short": "blocks of %d rows round-robin over %d ranks + 1 gather" % (part0.block, world) if world > 1 else "single GPU",
                        "width": W, "height": H, "rays_per_pixel": spp, "n_objects": cfg["n"],
                        "partition": ("blocks of %d rows dealt out round-robin (rank r renders blocks r, r + %d, ...: whole 8x8 ray tiles), "
                                      "one gather to rank 0 inside the timed region" % (part0.block, world)) if world > 1 else "single GPU",
@@ -773,8 +848,9 @@ def main():
                                               "sweep (which scans the list as the reference does) / the same CPU rate"}
         if log:
             line["log"] = log
-        line["summary"] = summary_of(line)          # last: the line is ~50 KB, a record that keeps only the tail of stdout still shows this
-        print(json.dumps(line), flush=True)
+        detail = write_detail(line, args.detail_out, world)
+        sys.stdout.flush()
+        print(compact_line(line, detail), flush=True)          # ONE line, < 2000 characters; the full record is in `detail`
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

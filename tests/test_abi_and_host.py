@@ -411,3 +411,34 @@ def test_bench_roofline_object_is_a_fraction_of_a_real_ceiling(tmp_path, monkeyp
     # the CPU baseline states the parallelism it may use: min(affinity, cgroup quota)
     n, how, quota = b.cpu_threads_available()
     assert n >= 1 and "sched_getaffinity" in how
+    # the ONE stdout line: compact (< 2000 characters whatever the record holds), every contract key, roofline + cpu_baseline objects
+    other = [{"config": c, "leg": leg, "rays_per_pixel": 64, "value": 456.789, "ms_per_step": 36.3, "roofline": r, "workload": "x" * 500,
+              "band_rate_over_full_frame_rate": 0.99} for c, leg in (("C3", "C3"), ("C3", "C3band"), ("C4", "C4band"), ("C5", "C5"), ("C5", "C5band"),
+                                                                        ("J1", "J1"))]
+    full = {"metric": "Mrays/s (primary rays, whole node), 10k-sphere 1080p 64spp", "value": 2614.3456789, "unit": "Mrays/s", "n_gpus": 1, "steps": 20,
+            "warmup": 5, "ms_per_step": 50.7623456, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": {"workload": "w" * 300, "workload_short": "C2: 10k random spheres (scene seed 1), 1920x1080, 64 spp",
+                                            "partition_short": "single GPU", "width": 1920, "height": 1080, "rays_per_pixel": 64, "n_objects": 10000},
+            "segments_per_primary_ray": 2.11326741, "image_mean": 0.118618046039477, "roofline": r, "other_configs": other,
+            "lds_sweep": {"value": 304.6}, "partition_balance": {"max_over_mean": 1.0134},
+            "cpu_baseline": {"value": 0.0669438, "unit": "Mrays/s", "cores": 15.4, "kind": "port", "sample": "s" * 400,
+                             "sample_short": "every 2th row+column of the C2 1080p frame (518400 px, 1 spp), C port of the CPU path, 16 threads, 27 s",
+                             "threads_started": 16, "single_thread_Mrays_s": 0.00435632, "faithful_Mrays_s": 0.0068229, "seconds": 26.9},
+            "speedup_vs_cpu": {"primary_rays": 39052.1, "like_for_like_linear_scan": 4550.2}, "log": ["l" * 1000] * 20}
+    text = b.compact_line(full, "gpurun_out/bench_detail_n1.json")
+    ln = json.loads(text)
+    assert len(text) < 2000 and "\n" not in text
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "other_configs", "detail"):
+        assert key in ln, key
+    assert ln["roofline"]["bound"] == "valu" and abs(ln["roofline"]["frac"] - r["frac"]) < 1e-3 * r["frac"] and len(ln["roofline"]["stages"]) == 2
+    assert abs(ln["roofline"]["traffic"] - r["traffic"]) < 1e-3 * r["traffic"] and ln["cpu_baseline"]["kind"] == "port"
+    assert list(ln["other_configs"]) == ["C3", "C3band", "C4band", "C5", "C5band", "J1"] and ln["value"] == 2614.35
+    # a record that would not fit loses its extras, never the contract keys
+    full["cpu_baseline"]["sample_short"] = "s" * 700
+    ln2 = json.loads(b.compact_line(full, "d.json"))
+    assert "other_configs" not in ln2 and "roofline" in ln2 and "cpu_baseline" in ln2
+    # the full record goes to a file
+    path = b.write_detail(full, str(tmp_path / "sub" / "detail.json"), 1)
+    assert path == os.path.join("sub", "detail.json")               # relative to the repo root (monkeypatched above) when inside it
+    assert json.load(open(tmp_path / path))["log"] == full["log"]

@@ -1210,8 +1210,21 @@ def _bench(args, timeout=900, launcher=None, env=None):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == 1 and out.stdout.rstrip().splitlines()[-1] == lines[0], out.stdout[-2000:]    # ONE JSON line, and it is the last line
+    # what a record that keeps only a tail of stdout can still parse (r03: a 53 KB line went unparsed)
+    assert len(lines[0]) < 2000 and json.loads(out.stdout[-2000:].splitlines()[-1]) == json.loads(lines[0])
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "detail"):
+        assert key in line, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    assert "workload" in line["config"]
+    d = json.load(open(os.path.join(ROOT, line["detail"]) if not os.path.isabs(line["detail"]) else line["detail"]))
+    # every figure of the line is a rounded copy of the full record's
+    assert abs(line["value"] - d["value"]) <= 1e-5 * d["value"] and abs(line["roofline"]["frac"] - d["roofline"]["frac"]) <= 1e-3 * d["roofline"]["frac"]
+    d["_line"] = line
+    return d
 
 
 def _check_roofline(r):
@@ -1235,7 +1248,8 @@ def test_bench_line_contract(gpu):
     """bench.py at a reduced sample count (counters off: they are the next test): one JSON line with the contract's keys,
     strong scaling by default, roofline objects that are fractions of a real ceiling for the value kernel, the LDS sweep
     and the three other configs, a cpu_baseline on the benchmark's own view, and the two kernels' frames bit-identical."""
-    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1,C5band=1", "--no-pmc"])
+    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1,C5band=1", "--no-pmc",
+                "--detail-out", "gpurun_out/test_bench_detail.json"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs", "lds_sweep"):
         assert key in d, key
@@ -1259,8 +1273,15 @@ def test_bench_line_contract(gpu):
     assert d["speedup_vs_cpu"]["like_for_like_linear_scan"] > 10          # the LDS sweep scans the list as the CPU does
     assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5", "C5"]
     assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, False, True]
-    assert list(d)[-1] == "summary" and abs(d["summary"]["value_Mrays_s"] - d["value"]) < 0.06 and len(d["summary"]["other_configs"]) == 5
-    assert len(json.dumps(d["summary"])) < 4096                      # the tail of stdout a record keeps still shows it
+    # the stdout line: the contract's keys + roofline and cpu_baseline as objects, the other legs as rows of numbers
+    ln = d["_line"]
+    assert ln["detail"] == "gpurun_out/test_bench_detail.json"
+    for key in ("value", "unit", "cores", "kind", "sample", "threads_started", "single_thread_Mrays_s"):
+        assert key in ln["cpu_baseline"], key
+    assert ln["cpu_baseline"]["kind"] == "port" and len(ln["roofline"]["stages"]) == 2
+    assert list(ln["other_configs"]) == ["C3", "C3band", "C4band", "C5", "C5band"]
+    assert all(len(row) == len(ln["other_cols"]) for row in ln["other_configs"].values())
+    assert abs(ln["other_configs"]["C5"][0] - d["other_configs"][3]["value"]) <= 1e-3 * d["other_configs"][3]["value"]
     bal = d["partition_balance"]
     assert len(bal["segments_per_band"]) == 8 and 1.0 <= bal["max_over_mean"] < 1.1        # blocks of 8 rows round-robin balance the frame
     assert d["other_configs"][1]["band_rate_over_full_frame_rate"] > 0

@@ -1,18 +1,20 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the bench line (with its live rocprofv3 counter passes), then the rocprofv3 kernel-trace
 # summary of the same command.  Outputs under gpurun_out/$TAG/; tools/store_profiles.py copies the judged files to profiles/.
-#   tools/gpu_profile.sh r03
+#   tools/gpu_profile.sh r04
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 echo "[gpu_profile] bench.py (N=1, default flags)"
-python bench.py --steps 3 --warmup 1 > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail -30 $OUT/bench_n1.err; exit 1; }
+python bench.py --steps 3 --warmup 1 --detail-out $OUT/bench_detail_n1.json > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail -30 $OUT/bench_n1.err; exit 1; }
 python - <<PY
 import json
-d = json.load(open("$OUT/bench_n1.json"))
+line = open("$OUT/bench_n1.json").read().strip().splitlines()[-1]
+print("compact line: %d characters" % len(line)); json.loads(line)
+d = json.load(open("$OUT/bench_detail_n1.json"))
 r = d["roofline"]
 iss = (r.get("issued") or {}).get("frac")
 print("value %.1f Mrays/s  %.2f ms/step  useful frac %.3f  issued frac %s  lane_util %s  valu_busy %s  hbm_frac %s  cpu %.4f Mrays/s (%s threads' worth) x%.0f" % (
@@ -36,7 +38,7 @@ find $OUT/trace -name "*kernel_stats.csv" | head -3
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 head -8 "$f" | cut -c1-200
 
-for leg in "C3 8" "C5 4 band"; do
+for leg in "C3 64" "C5 4 band"; do
   set -- $leg
   echo "[gpu_profile] rocprofv3 --kernel-trace --stats of $leg"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$1 -- python3 $R/tools/ab_kernels.py $1 $2 0 $3 > $OUT/trace_$1.log 2>&1 || { tail -20 $OUT/trace_$1.log; exit 1; }

@@ -14,7 +14,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(ROOT, "gpurun_out", tag)
 P = os.path.join(ROOT, "profiles")
 
@@ -22,8 +22,9 @@ spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "benc
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 
-line = json.load(open(os.path.join(G, "bench_n1.json")))
+line = json.load(open(os.path.join(G, "bench_detail_n1.json")))                 # the full record; bench_n1.json = the compact stdout line
 shutil.copy(os.path.join(G, "bench_n1.json"), os.path.join(P, "%s_bench_n1.json" % tag))
+shutil.copy(os.path.join(G, "bench_detail_n1.json"), os.path.join(P, "%s_bench_detail_n1.json" % tag))
 stats = max(glob.glob(os.path.join(G, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
 
@@ -49,7 +50,7 @@ if line.get("lds_sweep", {}).get("roofline", {}).get("counters"):
     legs_pk["C2:%d:full:2" % spp] = per_kernel(line["lds_sweep"]["roofline"])
 for o in line.get("other_configs", []):
     if o["roofline"].get("counters"):
-        s = int(o["workload"].split(" at ")[1].split(" spp")[0])
+        s = o["rays_per_pixel"]
         key = "%s:%d:%s:0" % (o["config"], s, "band" if "band" in o["workload"] else "full")
         legs[key] = o["roofline"]["counters"]
         legs_pk[key] = per_kernel(o["roofline"])
