@@ -108,7 +108,17 @@ typedef struct RtxConfig {
 
 /* RtxConfig.tuning.  Every combination renders the same bits (tests/test_gpu_parity.py::test_ab_knobs_keep_the_bits);
  * the library reads no environment variable for any of this.  The two tree-build fields (TRI_LEAF, BVH_MEDIAN) are read
- * when the tree is built (rtx_scene_upload / rtx_scene_append_objects / rtx_render), the others per render. */
+ * when the tree is built (rtx_scene_upload / rtx_scene_append_objects / rtx_render), the others per render.
+ *
+ * Product and lab.  librtx_hip.so holds the kernels RTX_KERNEL_AUTO can reach plus RTX_KERNEL_EXACT / RTX_KERNEL_MIXED.  The
+ * experiments that lost (profiles/LAB_NOTEBOOK.md) are compiled only into librtx_hip_lab.so -- the same sources with -DRTX_LAB,
+ * the same ABI, loaded by the lab tests and A/B tools.  In the product library
+ *   - a tuning word with a bit of RTX_TUNE_LAB_MASK (or a bit this header does not name) is refused with RTX_ERR_UNSUPPORTED by
+ *     every entry point that takes a config;
+ *   - RTX_KERNEL_BVH, RTX_KERNEL_BVH_REGROUP and RTX_KERNEL_WAVEFRONT each run the tree kernel that exists for the scene's tree
+ *     (sphere tree: trace_sph_packet_kernel / trace_bvh_spheres_kernel; a tree that holds triangles: trace_bvh_mesh_kernel, as
+ *     RTX_KERNEL_WAVEFRONT with the packet kernels in front); RtxStats.kernel reports the id whose kernels ran.  The lab library
+ *     keeps one kernel family per (id, tree kind) pair, as the enumerators' comments describe. */
 enum {
     RTX_TUNE_NO_TILES    = 1u << 0,  /* BVH kernels: ray queue in image rows instead of 8x8 pixel tiles (no packets then) */
     RTX_TUNE_BVH_CLASSIC = 1u << 1,  /* round 1's trace_bvh_kernel / trace_bvh_regroup_kernel instead of the f32-only steps */
@@ -135,6 +145,11 @@ enum {
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };
+
+#define RTX_TUNE_LAB_MASK (RTX_TUNE_BVH_CLASSIC | RTX_TUNE_NO_QNODES | RTX_TUNE_NO_PACKETS | RTX_TUNE_WF_PURE | RTX_TUNE_PK_LDS_STACK | \
+                           RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR | RTX_TUNE_BEAMS | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_SORT_SURVIVORS)
+#define RTX_TUNE_KNOWN_MASK (RTX_TUNE_LAB_MASK | RTX_TUNE_NO_TILES | RTX_TUNE_ONE_STAGE | RTX_TUNE_TWO_STAGE | RTX_TUNE_BVH_MEDIAN | \
+                             (15u << RTX_TUNE_TRI_LEAF_SHIFT) | (127u << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT)
 
 /* Camera (camera.rs:7-15).  to_world_space / to_cam_space are the three ROWS of each matrix
  * (mat.rs:11-18), row-major.  Only fov, position and to_world_space are read by render
@@ -200,6 +215,7 @@ RTX_STATIC_ASSERT(sizeof(RtxStats) == 104 && offsetof(RtxStats, trace_ms) == 32 
 int32_t     rtx_version(void);
 const char *rtx_last_error(void);
 int32_t     rtx_device_count(void);     /* number of usable gfx950 devices (0 when none) */
+int32_t     rtx_lab_build(void);        /* 0: librtx_hip.so (the product); 1: librtx_hip_lab.so (built with -DRTX_LAB, see RtxConfig.tuning) */
 
 /* Camera::new (camera.rs:19-28, derive_to_world_space_mat :42-49, Mat3x3::inverse
  * specific_math.rs:10-14).  Host-side, f64, reference operation order. */
@@ -285,7 +301,9 @@ int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t 
                                   uint8_t *d_rgb8, int32_t device, void *stream);
 
 /* Test hook: evaluates one f64 operation per element on the device (op 0: a/b, 1: sqrt(a),
- * 2: sin(a), 3: cos(a)); a, b, out are HOST arrays of n doubles.  Used by tests/ to check that the
+ * 2: sin(a), 3: cos(a), 4 / 5: sincos(a)'s two results; 6: the packet walks' v_writelane -- out[i] = (int)b[0] in lane (int)b[1]
+ * of every wave, (int)a[i] elsewhere; 7 / 8: v_min_f64 / v_max_f64 on the raw bits of a[i], b[i] -- the child sort's (key, link)
+ * pairs are denormal f64 patterns when the key is +0.0 and must come back bit for bit); a, b, out are HOST arrays of n doubles.  Used by tests/ to check that the
  * device's / and sqrt are correctly rounded and to measure how far its sin/cos are from libm. */
 int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n);
 

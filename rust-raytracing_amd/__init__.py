@@ -24,7 +24,7 @@ from .abi import (RTX_TUNE_NO_TILES, RTX_TUNE_BVH_CLASSIC, RTX_TUNE_NO_QNODES, R
 from .abi import (OBJECT_DTYPE, RTX_KERNEL_WAVEFRONT, RTX_KERNEL_AUTO, RTX_KERNEL_BVH, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH_REGROUP,
                   RTX_PLANE, RTX_SPHERE, RTX_TRIANGLE, RtxError, load_library)
 
-__all__ = ["Vector3", "Material", "Sphere", "Plane", "Triangle", "Object", "Config", "Camera", "Scene",
+__all__ = ["LabKernel", "Vector3", "Material", "Sphere", "Plane", "Triangle", "Object", "Config", "Camera", "Scene",
            "SceneHandle", "RtxError", "device_count", "pack_objects", "OBJECT_DTYPE",
            "RTX_KERNEL_AUTO", "RTX_KERNEL_EXACT", "RTX_KERNEL_MIXED", "RTX_KERNEL_MIXED_VERIFY", "RTX_KERNEL_BVH", "RTX_KERNEL_BVH_REGROUP", "RTX_KERNEL_WAVEFRONT", "debug_host_scene"]
 
@@ -159,9 +159,17 @@ def pack_objects(objects):
 # ---------------------------------------------------------------------------------------------
 # Config (scene.rs:16-65) + the build's seed / kernel fields
 # ---------------------------------------------------------------------------------------------
+class LabKernel(int):
+    """A RTX_KERNEL_* id that asks for the lab library's kernel family of that id (the test suite's loops over kernel ids)."""
+    lab = True
+
+    def __repr__(self):
+        return "lab:%d" % int(self)
+
+
 class Config:
     def __init__(self, rays_per_pixel=16, max_bounces=10, focal_length=10.0, focal_offset=1e-4,
-                 non_focal_offset=1e-1, seed=42, kernel=RTX_KERNEL_AUTO, tuning=0):   # Default, scene.rs:55-65
+                 non_focal_offset=1e-1, seed=42, kernel=RTX_KERNEL_AUTO, tuning=0, lab=False):   # Default, scene.rs:55-65
         self.rays_per_pixel = int(rays_per_pixel)
         self.max_bounces = int(max_bounces)
         self.focal_length = float(focal_length)
@@ -170,6 +178,12 @@ class Config:
         self.seed = int(seed)
         self.kernel = int(kernel)
         self.tuning = int(tuning)                                   # RTX_TUNE_* bits (A/B switches; 0 = what ships)
+        # harness only (not part of RtxConfig): render through librtx_hip_lab.so; a kernel id wrapped in LabKernel asks for it too
+        self.lab = bool(lab) or bool(getattr(kernel, "lab", False))
+
+    def wants_lab(self):
+        """Does this config need the lab library?  (asked for, or a tuning bit the product library refuses)"""
+        return self.lab or (self.tuning & abi.RTX_TUNE_LAB_MASK) != 0
 
     @staticmethod
     def default():
@@ -177,7 +191,7 @@ class Config:
 
     def _with(self, **kw):                                          # reassign!, scene.rs:29-37
         c = Config(self.rays_per_pixel, self.max_bounces, self.focal_length, self.focal_offset,
-                   self.non_focal_offset, self.seed, self.kernel, self.tuning)
+                   self.non_focal_offset, self.seed, self.kernel, self.tuning, self.lab)
         for k, v in kw.items():
             setattr(c, k, v)
         return c
@@ -205,6 +219,9 @@ class Config:
 
     def with_tuning(self, v):
         return self._with(tuning=int(v))
+
+    def with_lab(self, v=True):
+        return self._with(lab=bool(v))
 
     def to_c(self):
         return abi.RtxConfig(self.rays_per_pixel, self.max_bounces, self.focal_length, self.focal_offset,
@@ -311,11 +328,12 @@ class Scene:
         out = np.zeros((height, width, 3), dtype=np.float64)
         packed = self.packed()
         sc = _scene_c(self.config, self.camera, packed)
+        lib = load_library(self.config.wants_lab())
         if devices is None:
-            abi.check(load_library().rtx_render(C.byref(sc), width, height, out.ctypes.data))
+            abi.check(lib.rtx_render(C.byref(sc), width, height, out.ctypes.data), lib)
         else:
             dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
-            abi.check(load_library().rtx_render_devices(C.byref(sc), width, height, dv, len(devices), out.ctypes.data))
+            abi.check(lib.rtx_render_devices(C.byref(sc), width, height, dv, len(devices), out.ctypes.data), lib)
         return out
 
     def render_to_image(self, width, height, devices=None):         # scene.rs:172-178
@@ -324,50 +342,58 @@ class Scene:
         out = np.zeros((height, width, 3), dtype=np.uint8)
         packed = self.packed()
         sc = _scene_c(self.config, self.camera, packed)
+        lib = load_library(self.config.wants_lab())
         if devices is None:
-            abi.check(load_library().rtx_render_to_image(C.byref(sc), width, height, out.ctypes.data))
+            abi.check(lib.rtx_render_to_image(C.byref(sc), width, height, out.ctypes.data), lib)
         else:
             dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
-            abi.check(load_library().rtx_render_to_image_devices(C.byref(sc), width, height, dv, len(devices), out.ctypes.data))
+            abi.check(lib.rtx_render_to_image_devices(C.byref(sc), width, height, dv, len(devices), out.ctypes.data), lib)
         return out
 
-    def upload(self, device=0):
-        return SceneHandle(self, device)
+    def upload(self, device=0, lab=None):
+        """lab: None = the library the config asks for (Config.wants_lab()); True = librtx_hip_lab.so whatever the config says."""
+        return SceneHandle(self, device, lab)
 
 
 class SceneHandle:
     """Split form of the C ABI: scene resident on one device, rows rendered into device buffers."""
 
-    def __init__(self, scene, device=0):
-        self._lib = load_library()
+    def __init__(self, scene, device=0, lab=None):
+        self.lab = scene.config.wants_lab() if lab is None else bool(lab)
+        self._lib = load_library(self.lab)
         self.device = int(device)
         self._h = C.c_void_p()
         packed = scene.packed()
         sc = _scene_c(scene.config, scene.camera, packed)
-        abi.check(self._lib.rtx_scene_upload(C.byref(sc), self.device, C.byref(self._h)))
+        self._check(self._lib.rtx_scene_upload(C.byref(sc), self.device, C.byref(self._h)))
+
+    def _check(self, status):
+        abi.check(status, self._lib)                    # (the error string is thread-local in the library that set it)
 
     def set_config(self, config):
+        if config.wants_lab() and not self.lab:
+            raise ValueError("this handle lives in the product library; a lab config needs scene.upload(lab=True)")
         c = config.to_c()
-        abi.check(self._lib.rtx_scene_set_config(self._h, C.byref(c)))
+        self._check(self._lib.rtx_scene_set_config(self._h, C.byref(c)))
 
     def set_scratch_limit(self, n_bytes):
         """Upper bound of the handle's per-render scratch (0 = default); larger frames are traced in sample batches, same bits."""
-        abi.check(self._lib.rtx_scene_set_scratch_limit(self._h, int(n_bytes)))
+        self._check(self._lib.rtx_scene_set_scratch_limit(self._h, int(n_bytes)))
 
     def set_camera(self, camera):
         c = camera.to_c()
-        abi.check(self._lib.rtx_scene_set_camera(self._h, C.byref(c)))
+        self._check(self._lib.rtx_scene_set_camera(self._h, C.byref(c)))
 
     def append_objects(self, packed):
         """Scene::add_object (scene.rs:126-128) for a resident scene: `packed` is an OBJECT_DTYPE array (or a list of Objects)."""
         arr = packed if isinstance(packed, np.ndarray) else pack_objects(packed)
         arr = np.ascontiguousarray(arr, dtype=OBJECT_DTYPE)
-        abi.check(self._lib.rtx_scene_append_objects(self._h, arr.ctypes.data, len(arr)))
+        self._check(self._lib.rtx_scene_append_objects(self._h, arr.ctypes.data, len(arr)))
 
     def render_rows(self, width, height, row_begin, row_stride, n_rows, d_out_ptr, stream=None, want_stats=True):
         """d_out_ptr: device address of n_rows*width*3 doubles (e.g. a torch tensor's data_ptr())."""
         stats = abi.RtxStats()
-        abi.check(self._lib.rtx_render_rows(self._h, int(width), int(height), int(row_begin), int(row_stride),
+        self._check(self._lib.rtx_render_rows(self._h, int(width), int(height), int(row_begin), int(row_stride),
                                             int(n_rows), C.c_void_p(int(d_out_ptr)),
                                             C.c_void_p(int(stream)) if stream else None,
                                             C.byref(stats) if want_stats else None))
@@ -376,7 +402,7 @@ class SceneHandle:
     def render_blocks(self, width, height, block_rows, part, n_parts, d_out_ptr, stream=None, want_stats=True):
         """The band of part `part` of `n_parts` (blocks of `block_rows` rows dealt out round-robin) into device memory."""
         stats = abi.RtxStats()
-        abi.check(self._lib.rtx_render_blocks(self._h, int(width), int(height), int(block_rows), int(part), int(n_parts),
+        self._check(self._lib.rtx_render_blocks(self._h, int(width), int(height), int(block_rows), int(part), int(n_parts),
                                               C.c_void_p(int(d_out_ptr)), C.c_void_p(int(stream)) if stream else None,
                                               C.byref(stats) if want_stats else None))
         return stats if want_stats else None
@@ -384,7 +410,7 @@ class SceneHandle:
     def close(self):
         if self._h:
             h, self._h = self._h, C.c_void_p()
-            abi.check(self._lib.rtx_scene_free(h))      # non-zero: an earlier asynchronous render on the handle had failed
+            self._check(self._lib.rtx_scene_free(h))      # non-zero: an earlier asynchronous render on the handle had failed
 
     def __del__(self):
         try:

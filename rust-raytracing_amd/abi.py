@@ -10,6 +10,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(HERE, "librtx_hip.so")   # RTX_HIP_LIB: A/B builds
+# the lab library: same sources with -DRTX_LAB, same ABI, + the experiments behind RTX_TUNE_LAB_MASK bits and the older kernel
+# families (include/rtx_hip.h, "Product and lab").  Loaded only for a Config that asks for it (Config.lab / a lab tuning bit).
+LAB_LIB_PATH = os.environ.get("RTX_HIP_LAB_LIB") or os.path.join(HERE, "librtx_hip_lab.so")
 
 RTX_SPHERE, RTX_PLANE, RTX_TRIANGLE = 0, 1, 2
 RTX_KERNEL_AUTO, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH, RTX_KERNEL_BVH_REGROUP = 0, 1, 2, 3, 4, 5
@@ -25,6 +28,10 @@ RTX_TUNE_STAGE2_PAIR = 1 << 22
 RTX_TUNE_NO_CUT = 1 << 23
 RTX_TUNE_BEAMS = 1 << 24
 RTX_TUNE_INLINE_LEAVES = 1 << 25
+RTX_TUNE_LAB_MASK = (RTX_TUNE_BVH_CLASSIC | RTX_TUNE_NO_QNODES | RTX_TUNE_NO_PACKETS | RTX_TUNE_WF_PURE | RTX_TUNE_PK_LDS_STACK |
+                     RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR | RTX_TUNE_BEAMS | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_SORT_SURVIVORS)
+RTX_TUNE_KNOWN_MASK = (RTX_TUNE_LAB_MASK | RTX_TUNE_NO_TILES | RTX_TUNE_ONE_STAGE | RTX_TUNE_TWO_STAGE | RTX_TUNE_BVH_MEDIAN |
+                       (15 << RTX_TUNE_TRI_LEAF_SHIFT) | (127 << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT)
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)
@@ -64,6 +71,7 @@ SYMBOLS = [
     ("rtx_version", C.c_int32, []),
     ("rtx_last_error", C.c_char_p, []),
     ("rtx_device_count", C.c_int32, []),
+    ("rtx_lab_build", C.c_int32, []),
     ("rtx_camera_new", C.c_int32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(RtxCamera)]),
     ("rtx_render", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.c_void_p]),
     ("rtx_render_to_image", C.c_int32, [C.POINTER(RtxScene), C.c_uint32, C.c_uint32, C.c_void_p]),
@@ -93,7 +101,7 @@ class RtxError(RuntimeError):
         self.status = status
 
 
-_lib = None
+_libs = {}
 
 
 def _share_hip_runtime_with_torch():
@@ -116,26 +124,29 @@ def _share_hip_runtime_with_torch():
             pass
 
 
-def load_library():
-    """dlopen librtx_hip.so and bind every entry point.  Raises if the library is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(lab=False):
+    """dlopen librtx_hip.so (lab=True: librtx_hip_lab.so) and bind every entry point.  Raises if the library is absent."""
+    lab = bool(lab)
+    if lab in _libs:
+        return _libs[lab]
+    path = LAB_LIB_PATH if lab else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            "librtx_hip.so is not built (%s). Build it with `python rust-raytracing_amd/build.py` "
-            "(hipcc, gfx950). There is no CPU fallback for the render path." % LIB_PATH)
+            "%s is not built (%s). Build it with `python rust-raytracing_amd/build.py` "
+            "(hipcc, gfx950). There is no CPU fallback for the render path." % (os.path.basename(path), path))
     _share_hip_runtime_with_torch()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)                   # RTLD_LOCAL: the two libraries export the same names and stay apart
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
+    if "RTX_HIP_LIB" not in os.environ and "RTX_HIP_LAB_LIB" not in os.environ and int(lib.rtx_lab_build()) != int(lab):
+        raise RuntimeError("%s reports rtx_lab_build() = %d" % (path, int(lib.rtx_lab_build())))
+    _libs[lab] = lib
     return lib
 
 
-def check(status):
+def check(status, lib=None):
     if status != 0:
-        msg = load_library().rtx_last_error()
+        msg = (lib or load_library()).rtx_last_error()
         raise RtxError(status, msg.decode("utf-8", "replace") if msg else "")

@@ -144,9 +144,20 @@ void apply_config(RtxSceneHandle_ *h, const RtxConfig &cfg)
     h->sv_dirty = true;
 }
 
+#ifdef RTX_LAB
+constexpr bool kLabBuild = true;
+#else
+constexpr bool kLabBuild = false;
+#endif
+
 int32_t check_config(const RtxConfig &cfg)
 {
     if (cfg.kernel > RTX_KERNEL_WAVEFRONT) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.kernel: unknown kernel id");
+    if (cfg.tuning & ~(uint32_t)RTX_TUNE_KNOWN_MASK)
+        return fail(RTX_ERR_UNSUPPORTED, "RtxConfig.tuning: a bit include/rtx_hip.h does not name");
+    if (!kLabBuild && (cfg.tuning & (uint32_t)RTX_TUNE_LAB_MASK))
+        return fail(RTX_ERR_UNSUPPORTED, "RtxConfig.tuning: a RTX_TUNE_LAB_MASK bit selects a kernel that exists in librtx_hip_lab.so only "
+                                         "(this is the product library)");
     if (cfg.max_bounces == UINT64_MAX)       // max_bounces + 1 overflows in the reference (scene.rs:227)
         return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.max_bounces + 1 overflows");
     if (cfg.rays_per_pixel > 0xFFFFFFFFull) return fail(RTX_ERR_INVALID_ARGUMENT, "RtxConfig.rays_per_pixel exceeds 2^32-1");
@@ -392,6 +403,11 @@ int32_t pack_scene(const RtxScene *scene, PackedScene &p)
                      (bvh.has_tris && !bvh.has_spheres && tree_recs[1].empty() && tree_recs[0].empty() ? 4u : 0u);
     if ((p.sv.bvh_flags & 4u) && build_qnodes(bvh4, p.qnodes)) p.sv.bvh_flags |= 8u;
     else p.qnodes.clear();
+#ifndef RTX_LAB
+    // the product library holds the pure-footprint kernels in their 64-byte-node instances only: a tree whose nodes have no such
+    // form (coordinates beyond the quantisation's range) walks as a joint tree, which takes any node
+    if ((p.sv.bvh_flags & 12u) == 4u) p.sv.bvh_flags &= ~4u;
+#endif
     if ((p.sv.bvh_flags & 3u) == 1u && build_q3nodes(bvh4, bvh.abs_pad, p.q3nodes)) p.sv.bvh_flags |= 16u;     // spheres only
     else p.q3nodes.clear();
     if (debug_prints())
@@ -558,6 +574,8 @@ int32_t rtx_version(void) { return RTX_HIP_VERSION; }
 const char *rtx_last_error(void) { return g_last_error.c_str(); }
 
 int32_t rtx_device_count(void) { return usable_device_count(); }
+
+int32_t rtx_lab_build(void) { return kLabBuild ? 1 : 0; }
 
 int32_t rtx_camera_new(const double position[3], const double direction[3], double fov, RtxCamera *out)
 {
@@ -726,10 +744,22 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         }
     }
 
-    // the wavefront form exists for pure (x, y)-footprint triangle trees and for trees that hold spheres only; any other
+#ifndef RTX_LAB
+    // the product library: ONE tree-kernel family per kind of tree, whichever of the three tree ids was asked for (include/rtx_hip.h,
+    // "Product and lab") -- a sphere tree (with its 64-byte nodes) runs the sphere kernels, a tree that holds triangles the mesh
+    // kernel (behind the packet kernels when RTX_KERNEL_WAVEFRONT can take it), no tree the LDS sweep
+    if (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP || kernel == RTX_KERNEL_WAVEFRONT) {
+        const bool sphere_tree = h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 19u) == 17u;
+        const bool tri_tree = h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 2u) != 0u;
+        if (sphere_tree) kernel = RTX_KERNEL_BVH;
+        else if (!tri_tree) kernel = RTX_KERNEL_MIXED;
+        else if (kernel == RTX_KERNEL_BVH) kernel = RTX_KERNEL_BVH_REGROUP;
+    }
+#endif
+    // the wavefront form exists for pure (x, y)-footprint triangle trees and (lab) for trees that hold spheres only; any other
     // scene takes the regrouping kernel
     const bool wf_mesh = wavefront_mesh_supported(h->sv, want_tiles);
-    const bool wf_spheres = !wf_mesh && h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 3u) == 1u;
+    const bool wf_spheres = kLabBuild && !wf_mesh && h->sv.n_bvh_nodes != 0 && (h->sv.bvh_flags & 3u) == 1u;
     if (kernel == RTX_KERNEL_WAVEFRONT && !wf_mesh && !wf_spheres) kernel = RTX_KERNEL_BVH_REGROUP;
     // the BVH kernels' ray queue runs over 8x8 pixel tiles (a wave's 64 rays = one tile); a sample then has
     // tiles_x * tiles_y * 64 queue slots (the padding of partial tiles included), else npix
@@ -811,28 +841,43 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
     // RTX_TUNE_BVH_CLASSIC: trace_bvh_regroup_kernel)
     const bool mesh_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 2u) != 0u && !classic;
     // the regrouping schedule on a tree without triangle leaves: the pool kernel (RTX_TUNE_BVH_CLASSIC: round 1's)
+#ifdef RTX_LAB
     const bool pool_kernel = kernel == RTX_KERNEL_BVH_REGROUP && (h->sv.bvh_flags & 3u) == 1u && h->sv.n_bvh_nodes != 0 && !classic;
+#endif
     if (kernel == RTX_KERNEL_BVH || kernel == RTX_KERNEL_BVH_REGROUP) {
+#ifdef RTX_LAB
         const size_t need = pool_kernel ? bvh_spheres_pool_bytes(h->sv, h->n_cus)
                             : spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus)
                             : mesh_kernel ? bvh_mesh_spill_bytes(h->sv, h->n_cus) : bvh_spill_bytes(h->sv, h->n_cus);
+#else
+        if (!spheres_kernel && !mesh_kernel) return fail(RTX_ERR_HIP, "internal: no tree kernel for this scene (product dispatch)");
+        const size_t need = spheres_kernel ? bvh_spheres_spill_bytes(h->sv, h->n_cus) : bvh_mesh_spill_bytes(h->sv, h->n_cus);
+#endif
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
     }
     if (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY) {
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, mixed_state_bytes(h->n_cus))) return rc;
     }
     // the sphere kernel's two-stage form from 2^20 rays per launch on (RTX_TUNE_ONE_STAGE: one launch, for A/B runs)
+    // (the product's stage 1 exists as packets only: a queue that is not tiled, or a tree too deep for the wave-uniform stack, stays one stage)
     const bool spheres_two_stage = spheres_kernel && h->cfg.max_bounces > 0 && (tuning & RTX_TUNE_ONE_STAGE) == 0u &&
-                                   (batch * per_sample64 >= (1ull << 20) || (tuning & RTX_TUNE_TWO_STAGE) != 0u);
+                                   (batch * per_sample64 >= (1ull << 20) || (tuning & RTX_TUNE_TWO_STAGE) != 0u) &&
+                                   bvh_spheres_two_stage_ok(h->sv, tiled);
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
+#ifdef RTX_LAB
         if (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) {
             const size_t a = bvh_spheres_pool2_bytes(h->n_cus), b = bvh_spheres_pair_bytes(h->n_cus);
             if (int32_t rc = grow(&h->pool, &h->pool_bytes, a > b ? a : b)) return rc;
         }
+#endif
     }
     if (kernel == RTX_KERNEL_WAVEFRONT) {
+#ifdef RTX_LAB
         const size_t need = wf_mesh ? wavefront_spill_bytes(h->sv, h->n_cus) : wavefront_spheres_spill_bytes(h->sv, h->n_cus);
+#else
+        const size_t need = wavefront_spill_bytes(h->sv, h->n_cus);
+#endif
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, wavefront_state_bytes(batch * per_sample64, wavefront_levels(h->sv)))) return rc;
     }
@@ -875,26 +920,35 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
         } else if (kernel == RTX_KERNEL_WAVEFRONT) {
-            if (wf_mesh)
-                RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
-                                                     reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
-            else
+#ifdef RTX_LAB
+            if (!wf_mesh)
                 RTX_HIP_CHECK(launch_trace_wavefront_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
                                                              reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            else
+#endif
+                RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
+                                                     reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
+#ifdef RTX_LAB
             if (pool_kernel)
                 RTX_HIP_CHECK(launch_trace_bvh_spheres_pool(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                             h->state, h->n_cus, stream));
-            else if (mesh_kernel)
-                RTX_HIP_CHECK(launch_trace_bvh_mesh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
-                                                    reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
-            else
+            else if (!mesh_kernel)
                 RTX_HIP_CHECK(launch_trace_bvh_regroup(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            else
+#endif
+                RTX_HIP_CHECK(launch_trace_bvh_mesh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                                    reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else if (kernel == RTX_KERNEL_BVH) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
-            if (spheres_kernel)
+#ifdef RTX_LAB
+            if (!spheres_kernel)
+                RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
+                                               reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+            else
+#endif
                 RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus,
                                                        spheres_two_stage ? h->wf_state : nullptr,
@@ -902,9 +956,6 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                            ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u) | ((tuning & RTX_TUNE_STAGE2_PAIR) ? 8u : 0u), stream,
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
                                                        stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr));
-            else
-                RTX_HIP_CHECK(launch_trace_bvh(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
-                                               reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,

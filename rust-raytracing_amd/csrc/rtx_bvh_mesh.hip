@@ -380,17 +380,27 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     const uint32_t need_stack = 3u * sv.bvh_depth + 2u, lds_stack = (uint32_t)(wide ? kMeshStackQ : kMeshStack);
     const uint32_t spill_entries = spill && need_stack > lds_stack ? need_stack - lds_stack : 0u;
     // 0: a joint tree; 1: nothing but (x, y)-footprint triangles; 2: ... with the 64-byte nodes (RTX_TUNE_NO_QNODES: A/B runs)
+#ifdef RTX_LAB
     const bool no_q = (sv.tuning & RTX_TUNE_NO_QNODES) != 0u;
     const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : ((sv.bvh_flags & 8u) != 0u && !no_q ? 2 : 1);
+#else
+    // (the product holds instances 0 and 2: rtx_api.hip clears flag 4 of a pure footprint tree without 64-byte nodes)
+    if ((sv.bvh_flags & 12u) == 4u) return hipErrorInvalidValue;
+    const int plain = (sv.bvh_flags & 4u) == 0u ? 0 : 2;
+#endif
     void (*kernel)(const SceneView *, const RowsView *, double *, Counters *, unsigned long long *, const float4 *, const LeafArrays,
                    const MeshArrays, uint32_t *, uint32_t, uint32_t, const MeshRaySource) = nullptr;
     const bool deep = spill_entries != 0u;
     if (src) {
         if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2, true> : trace_bvh_mesh_kernel<false, 2, true>;
+#ifdef RTX_LAB
         else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1, true> : trace_bvh_mesh_kernel<false, 1, true>;
+#endif
         else kernel = deep ? trace_bvh_mesh_kernel<true, 0, true> : trace_bvh_mesh_kernel<false, 0, true>;
     } else if (plain == 2) kernel = deep ? trace_bvh_mesh_kernel<true, 2, false> : trace_bvh_mesh_kernel<false, 2, false>;
+#ifdef RTX_LAB
     else if (plain == 1) kernel = deep ? trace_bvh_mesh_kernel<true, 1, false> : trace_bvh_mesh_kernel<false, 1, false>;
+#endif
     else kernel = deep ? trace_bvh_mesh_kernel<true, 0, false> : trace_bvh_mesh_kernel<false, 0, false>;
     const float4 *nodes = plain == 2 ? reinterpret_cast<const float4 *>(sv.bvh_qnodes) : reinterpret_cast<const float4 *>(sv.bvh_nodes);
     MeshRaySource none{};

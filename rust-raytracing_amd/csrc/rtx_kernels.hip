@@ -15,6 +15,7 @@
 //
 // Compiled with -ffp-contract=off; the f32 filter uses explicit fmaf.
 #include "rtx_launch.h"
+#include "rtx_traverse.h"
 
 #include <cstdlib>
 
@@ -555,7 +556,15 @@ __global__ void debug_math_kernel(int op, const double *a, const double *b, doub
         case 1: r = sqrt(a[i]); break;
         case 2: r = sin(a[i]); break;
         case 3: r = cos(a[i]); break;
-        default: { double sn, cs; sincos(a[i], &sn, &cs); r = (op == 4) ? sn : cs; } break;
+        case 4: case 5: { double sn, cs; sincos(a[i], &sn, &cs); r = (op == 4) ? sn : cs; } break;
+        case 6:                                          // rtx_writelane (rtx_traverse.h): lane (int)b[1] of every wave takes (int)b[0]
+            r = (double)rtx_writelane(__builtin_amdgcn_readfirstlane((int)b[0]), __builtin_amdgcn_readfirstlane((int)b[1]), (int)a[i]);
+            break;
+        default: {                                       // 7 / 8: the child sort's v_min_f64 / v_max_f64 on raw bit patterns
+            double lo, hi;
+            rtx_minmax_f64_bits(a[i], b[i], lo, hi);
+            r = (op == 7) ? lo : hi;
+        } break;
     }
     out[i] = r;
 }

@@ -20,6 +20,7 @@ hipError_t launch_trace_mixed(const SceneView *d_sv, const SceneView &sv, const 
                               double *samples, double *state, Counters *counters, unsigned long long *work_counter,
                               int n_cus, bool verify, hipStream_t stream);
 
+#ifdef RTX_LAB       // round 1's lock-step kernel (rtx_bvh.hip): librtx_hip_lab.so only
 // BVH kernel: persistent waves, one ray per lane, per-lane stack traversal of the flat BVH (sphere boxes, triangle
 // footprints) with a conservative f32 slab test; leaves and the shapes outside the tree use the exact f64 tests.  work_counter: zeroed u64 ray-queue head.
 // spill: bvh_spill_bytes(sv, n_cus) bytes of device scratch for stack entries beyond the LDS stack (may be null when 0).
@@ -28,6 +29,7 @@ size_t bvh_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_bvh(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                             double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                             hipStream_t stream);
+#endif
 
 // RTX_KERNEL_BVH for trees that hold spheres only (rtx_bvh_spheres.hip): an f32-only traversal loop with conservative
 // distance bounds, the exact tests after the walk, 5 waves per SIMD.  spill: bvh_spheres_spill_bytes() bytes (may be 0).
@@ -38,16 +40,22 @@ size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
 // survive their first hit in a second one fed from a queue of 64-byte records), or null: one launch.  A survivor the queue
 // cannot take raises counters[1].pad_ (the launch's watchdog word, reported by the API).
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
+// may a launch run in two stages?  The product's stage 1 exists as packets only (tiled ray queue, a tree the wave-uniform stack
+// holds); the lab library falls back to per-lane primary rays (MODE 1) and always may.
+bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot = nullptr,
                                     hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr);
+#ifdef RTX_LAB
 // pool_mem: bvh_spheres_pool2_bytes(n_cus) bytes: stage 2 runs as a wave-local pool of ray slots (flags bit 2: the lock-step form)
 size_t bvh_spheres_pool2_bytes(int n_cus);
 size_t bvh_spheres_pair_bytes(int n_cus);      // flags bit 3: stage 2 with two rays per lane; pool_mem then holds this many bytes
+#endif
 // (stage1_snapshot: kCounterShards Counters that receive a copy of `counters` as stage 1 left them; stage1_done: recorded
 // after stage 1 -- both only for the two-stage form, both optional: what RtxStats' stage1_* fields are made of)
 
+#ifdef RTX_LAB       // librtx_hip_lab.so only: the pool kernel (rtx_bvh_spheres_pool.hip), round 1's regrouping kernel (rtx_bvh_regroup.hip)
 // RTX_KERNEL_BVH_REGROUP for trees that hold spheres only (rtx_bvh_spheres_pool.hip): every lane owns a pool of rays, the
 // f64 phase serves all of them, the walk runs the lane's pending segments one after the other with the waiting lanes
 // served together.  scratch: bvh_spheres_pool_bytes() bytes (the pools + the HBM stack columns).
@@ -61,6 +69,7 @@ hipError_t launch_trace_bvh_spheres_pool(const SceneView *d_sv, const SceneView 
 hipError_t launch_trace_bvh_regroup(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill,
                                     int n_cus, hipStream_t stream);
+#endif
 
 // RTX_KERNEL_BVH_REGROUP for trees that hold triangles (rtx_bvh_mesh.hip): the regrouping schedule with an f32-only
 // traversal step (certain-hit bounds, exact tests in the f64 phase).  spill: bvh_mesh_spill_bytes() bytes (may be 0).
@@ -95,12 +104,14 @@ size_t wavefront_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                   double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream);
 
+#ifdef RTX_LAB       // librtx_hip_lab.so only
 // RTX_KERNEL_WAVEFRONT for trees that hold spheres only (rtx_wavefront_spheres.hip): walk / shade kernels per bounce level,
 // the walk's lanes refilled from the level's queue.  state_mem: wavefront_state_bytes(); spill: wavefront_spheres_spill_bytes().
 size_t wavefront_spheres_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_wavefront_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                           double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus,
                                           hipStream_t stream);
+#endif
 
 // Folds the batch's samples into acc (scene.rs:253-259, iter_ops.rs:4-8: left fold from zeros in sample order).
 // samples: rv.n_rays 32-byte records in ray-queue order (store_sample, rtx_device.h); per_sample = queue slots

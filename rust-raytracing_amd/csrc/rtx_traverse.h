@@ -146,6 +146,27 @@ struct PkConstU32 {
 };
 __device__ __forceinline__ PkConstU32 pk_const(const uint32_t *p) { return PkConstU32{(const __attribute__((address_space(4))) uint32_t *)(uintptr_t)p}; }
 
+// v_writelane_b32: lane `lane` (wave-uniform) of `old` replaced by the wave-uniform `value` -- the packet walks keep their
+// wave-uniform stack in the lanes of one VGPR.  This clang has no __builtin_amdgcn_writelane; the LLVM intrinsic is reached by
+// its name.  That is a toolchain-version hazard, so it is guarded twice: the build refuses a clang major nobody has validated
+// (re-run tests/test_gpu_parity.py::test_writelane_and_f64_minmax_kats on the new toolchain, then extend the list or pass
+// -DRTX_WRITELANE_VALIDATED), and that test checks the instruction's semantics on the device through rtx_debug_math op 6.
+#if !defined(RTX_WRITELANE_VALIDATED) && defined(__clang_major__)
+static_assert(__clang_major__ == 22, "rtx_writelane binds llvm.amdgcn.writelane.i32 by name: validated with AMD clang 22 (ROCm 7.2) only");
+#endif
+extern "C" __device__ int rtx_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// The child sort's compare-exchange on (key, link) pairs packed as the high / low word of an f64 (sphere_node_step_q3).  Written as
+// instructions: the pairs are not canonical doubles and fmin() would quiet them first.  A key of +0.0 (the ray starts inside the
+// child's box: the common case) makes the pair an f64 DENORMAL whose whole payload is the link, so this relies on the kernels' f64
+// denormal mode being "preserve" -- the default for gfx950, needed by the reference's arithmetic anyway, and checked on the device
+// (rtx_debug_math ops 7 / 8, same test): a flushed pair would send the walk to node 0 for ever.
+__device__ __forceinline__ void rtx_minmax_f64_bits(double a, double b, double &lo, double &hi)
+{
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+}
+
 constexpr int kBvhQueue = 8;                // candidate shapes a lane may hold between two exact passes
 constexpr uint32_t kQueueTri = 0x80000000u; // queue entry: a triangle filter record (else a local sphere index)
 
@@ -572,8 +593,7 @@ __device__ __forceinline__ void sphere_step_q3(const float4 *__restrict__ qnodes
     double kd[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) kd[c] = __hiloint2double((int)__float_as_uint(key[c]), (int)lnk[c]);
-#define RTX_CSWAP(i, j) { double lo_, hi_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(kd[i]), "v"(kd[j])); \
-                          asm("v_max_f64 %0, %1, %2" : "=v"(hi_) : "v"(kd[i]), "v"(kd[j])); kd[i] = lo_; kd[j] = hi_; }
+#define RTX_CSWAP(i, j) { double lo_, hi_; rtx_minmax_f64_bits(kd[i], kd[j], lo_, hi_); kd[i] = lo_; kd[j] = hi_; }
     RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
 #pragma unroll
@@ -673,8 +693,7 @@ __device__ __forceinline__ void sphere_node_step_q3(const float4 *__restrict__ q
     }
     nbox += 4;
     // (key, link) pairs ordered as f64 values (sphere_step_q3)
-#define RTX_CSWAP(i, j) { double lo_, hi_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(kd[i]), "v"(kd[j])); \
-                          asm("v_max_f64 %0, %1, %2" : "=v"(hi_) : "v"(kd[i]), "v"(kd[j])); kd[i] = lo_; kd[j] = hi_; }
+#define RTX_CSWAP(i, j) { double lo_, hi_; rtx_minmax_f64_bits(kd[i], kd[j], lo_, hi_); kd[i] = lo_; kd[j] = hi_; }
     RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
     float key[4];
@@ -766,7 +785,7 @@ __device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf
     }
 }
 
-#ifdef RTX_SPH_PROFILE          // lab build (-DRTX_SPH_PROFILE=k): one per-lane count per build, summed and reported through exact_tests
+#if defined(RTX_LAB) && defined(RTX_SPH_PROFILE)          // lab build (-DRTX_SPH_PROFILE=k): one per-lane count per build, summed and reported through exact_tests
 #define RTX_PROF_ARG , unsigned long long &rtx_prof
 #else
 #define RTX_PROF_ARG
@@ -786,7 +805,7 @@ __device__ __forceinline__ void sphere_walk_phased(const float4 *__restrict__ qn
     while (node != kNone) {
         const bool at_leaf = (node >> 29) != 0u;
         const unsigned long long lm = __ballot(at_leaf), am = __ballot(true);
-#ifdef RTX_SPH_PROFILE
+#if defined(RTX_LAB) && defined(RTX_SPH_PROFILE)
         {   // lab build: 3 node-visit iterations, 4 lanes in them, 5 leaf-visit iterations, 6 lanes in them, 7 lanes in the loop
             const bool leafv = (uint32_t)__popcll(lm) >= leaf_lanes || lm == am;
             const bool leader = (uint32_t)(__ffsll((long long)am) - 1) == (tid & 63u);

@@ -34,7 +34,7 @@ namespace rtx {
 #ifndef RTX_WF_SERVICE
 #define RTX_WF_SERVICE 8
 #endif
-constexpr uint32_t kWfService = RTX_WF_SERVICE;                   // lanes of a wave that wait before they are served together
+[[maybe_unused]] constexpr uint32_t kWfService = RTX_WF_SERVICE;                   // lanes of a wave that wait before they are served together
 #ifndef RTX_WF_TRACE_WAVES
 #define RTX_WF_TRACE_WAVES 4
 #endif
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(const SceneView *__res
     st.rec[0][i] = w;
 }
 
+#ifdef RTX_LAB      // the per-lane walk kernel of the all-levels wavefront form (RTX_TUNE_WF_PURE, RTX_TUNE_NO_PACKETS): librtx_hip_lab.so only
 // ---- the walk ------------------------------------------------------------------------------------------------------------
 template <bool SPILL, int PLAIN>
 __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(const SceneView *__restrict__ svp, const WfState st,
@@ -205,6 +206,8 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
     }
 }
 
+#endif  // RTX_LAB
+
 // ---- the walk of level 0 as packets --------------------------------------------------------------------------------------
 // Level 0's queue is the launch's ray queue: 64 consecutive records are the primary rays of one 8x8 pixel tile of one
 // sample -- one origin (up to the aperture jitter), directions a few pixels apart.  They cross the same footprints, so
@@ -227,8 +230,7 @@ constexpr int kPkWavesJoint = RTX_PK_WAVES_JOINT;
 
 // (PkConst4 / pk_const / pk_bits: wave-uniform reads through the scalar cache, rtx_traverse.h)
 
-// v_writelane_b32 (this clang has no __builtin_amdgcn_writelane; the LLVM intrinsic is reached by its name)
-extern "C" __device__ int rtx_wf_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+// (rtx_writelane: rtx_traverse.h)
 
 // The wave-uniform stack of a packet walk in the lanes of ONE VGPR (v_writelane / v_readlane with a scalar index) when the
 // tree's depth allows it (3 * depth + 2 <= kPkLaneStack), else in LDS (lane 0 stores, exec-masked).  The packet kernels are
@@ -429,9 +431,9 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
 #undef RTX_CSWAP
             if (lane_stack) {
                 // three unconditional pushes, farthest first; an invalid one lands on the slot the next push overwrites
-                stk_v = rtx_wf_writelane((int)kl[3], (int)sp, stk_v); sp += key[3] < 0x7F800000u ? 1u : 0u;
-                stk_v = rtx_wf_writelane((int)kl[2], (int)sp, stk_v); sp += key[2] < 0x7F800000u ? 1u : 0u;
-                stk_v = rtx_wf_writelane((int)kl[1], (int)sp, stk_v); sp += key[1] < 0x7F800000u ? 1u : 0u;
+                stk_v = rtx_writelane((int)kl[3], (int)sp, stk_v); sp += key[3] < 0x7F800000u ? 1u : 0u;
+                stk_v = rtx_writelane((int)kl[2], (int)sp, stk_v); sp += key[2] < 0x7F800000u ? 1u : 0u;
+                stk_v = rtx_writelane((int)kl[1], (int)sp, stk_v); sp += key[1] < 0x7F800000u ? 1u : 0u;
             } else {
                 if (key[3] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[3]; sp += 1; }
                 if (key[2] < 0x7F800000u && sp < (uint32_t)kPkStack) { if (lane == 0) stk[sp] = kl[2]; sp += 1; }
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
     }
 }
 
+#ifdef RTX_LAB      // RTX_TUNE_BEAMS: librtx_hip_lab.so only
 // ---- the walk of level 0 as beams ------------------------------------------------------------------------------------------
 // The packet walk above opens ONE node per step for the whole wave: every lane tests its ray against the four rectangles, the
 // ordering and the stack are scalar code -- 369 such steps per C3 tile, ~60 VALU and ~70 SALU instructions each, and the kernel
@@ -699,6 +702,8 @@ __global__ __launch_bounds__(kBvhThreads, kBeamWaves) void wf_trace_beam_kernel(
     }
 }
 
+#endif  // RTX_LAB
+
 // ---- closest_object's exact part, ray_hit, the next segment's set-up ---------------------------------------------------------
 __global__ __launch_bounds__(kBvhThreads, kWfShadeWaves) void wf_shade_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
                                                                   const WfState st, uint32_t level, double *__restrict__ samples,
@@ -881,7 +886,9 @@ uint32_t wavefront_spill_entries(const SceneView &sv)
 bool wavefront_mesh_supported(const SceneView &sv, bool tiled)
 {
     if ((sv.bvh_flags & 2u) == 0u || sv.n_bvh_nodes == 0) return false;
-    if ((sv.bvh_flags & 4u) != 0u) return true;
+#ifdef RTX_LAB
+    if ((sv.bvh_flags & 4u) != 0u) return true;      // (the lab's per-lane walk kernel takes a pure footprint tree of any depth, tiled or not)
+#endif
     return tiled && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack;
 }
 
@@ -910,8 +917,12 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const bool deep = spill_entries != 0u;
     const float4 *nodes = reinterpret_cast<const float4 *>(sv.bvh_nodes);
     const float4 *qnodes = reinterpret_cast<const float4 *>(sv.bvh_qnodes);
+#ifdef RTX_LAB
     const bool qn = (sv.bvh_flags & 8u) != 0u && (sv.tuning & RTX_TUNE_NO_QNODES) == 0u;
+#endif
+#ifdef RTX_LAB
     const uint32_t trace_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfTraceWaves);
+#endif
     const uint32_t shade_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kWfShadeWaves);   // (grid-stride)
     auto generate = [&](const WfState &s0) {
         hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, s0);
@@ -925,29 +936,47 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     // per leaf and the queue-fed stage's own regrouping threshold it is level with the all-wavefront form even on C3 at
     // 1080p x 64 spp (322.6 against 322.9 ms), so that form runs only on request: RTX_TUNE_WF_PURE (tests, A/B runs).
     const bool joint = (sv.bvh_flags & 4u) == 0u;      // spheres and / or footprints of other planes in the tree: packets + megakernel only
-    const bool hybrid = joint || (sv.tuning & RTX_TUNE_WF_PURE) == 0u;
     // level 0 as packets: the ray queue in 8x8 tiles, a tree the wave-uniform stack can hold
+#ifdef RTX_LAB
+    const bool hybrid = joint || (sv.tuning & RTX_TUNE_WF_PURE) == 0u;
     const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack && (joint || (sv.tuning & RTX_TUNE_NO_PACKETS) == 0u);
     if (joint && !packets) return hipErrorInvalidValue;      // (wavefront_mesh_supported() keeps the caller from asking)
+#else
+    // the product: the hybrid with packets, nothing else (the per-lane walk kernel of the other forms is a lab kernel)
+    const bool hybrid = true;
+    const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack;
+    if (!packets) return hipErrorInvalidValue;               // (wavefront_mesh_supported() keeps the caller from asking)
+    (void)d_sv; (void)qnodes; (void)deep;
+#endif
     const float cmax_ru = std::nextafterf((float)sv.sphere_cmax, INFINITY);
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * (joint ? kPkWavesJoint : kPkWaves));
+#ifdef RTX_LAB
     // on request, a pure footprint tree: the tile's rays as ONE beam, the lanes across nodes (wf_trace_beam_kernel); any depth
     const bool beams = rv.tiles_x != 0u && !joint && (sv.tuning & RTX_TUNE_NO_PACKETS) == 0u && (sv.tuning & RTX_TUNE_BEAMS) != 0u;
     const uint32_t beam_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * kBeamWaves);
+#endif
     auto level_fn = [&](const WfState &sk, uint32_t level) {
+#ifdef RTX_LAB
         if (level == 0u && beams) {
             hipLaunchKernelGGL(wf_trace_beam_kernel, dim3(beam_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root);
-        } else if (level == 0u && packets) {
+        } else
+#endif
+        if (level == 0u && packets) {
             const uint32_t lane_stack = 3u * sv.bvh_depth + 2u <= (uint32_t)kPkLaneStack && (sv.tuning & RTX_TUNE_PK_LDS_STACK) == 0u ? 1u : 0u;
             if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
             else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
-        } else if (qn) {
+        }
+#ifdef RTX_LAB
+        else if (qn) {
             if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);
             else hipLaunchKernelGGL((wf_trace_kernel<false, 2>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, qnodes, ma, spill, spill_entries);
         } else {
             if (deep) hipLaunchKernelGGL((wf_trace_kernel<true, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, nodes, ma, spill, spill_entries);
             else hipLaunchKernelGGL((wf_trace_kernel<false, 1>), dim3(trace_blocks), dim3(kBvhThreads), 0, stream, d_sv, sk, level, counters, nodes, ma, spill, spill_entries);
         }
+#else
+        else return hipErrorInvalidValue;                    // (the product runs level 0 only, as packets)
+#endif
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(wf_shade_kernel, dim3(shade_blocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, sk, level, samples, counters, la,

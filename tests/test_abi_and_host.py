@@ -28,7 +28,35 @@ def test_library_exports_every_declared_symbol(rtx):
     assert set(declared) == bound                    # the Python binding covers the whole header
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rtx_version() == 100
+    assert lib.rtx_version() == 100 and lib.rtx_lab_build() == 0
+    lab = rtx.load_library(lab=True)                 # the lab library: the same ABI from the same sources with -DRTX_LAB
+    for name in declared:
+        assert getattr(lab, name) is not None
+    assert lab.rtx_version() == 100 and lab.rtx_lab_build() == 1
+
+
+def test_product_library_holds_only_what_auto_can_reach():
+    """include/rtx_hip.h, "Product and lab": librtx_hip.so = the kernels RTX_KERNEL_AUTO can reach + RTX_KERNEL_EXACT / MIXED and the
+    epilogues -- at most 25 kernel instances, none of the experiments (tools/kernel_instances.py reads the code objects); the lab
+    library holds them all.  A config check needs no GPU: the product refuses lab tuning bits, the lab library takes them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ki", os.path.join(ROOT, "tools", "kernel_instances.py"))
+    ki = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ki)
+    prod = ki.kernel_names(os.path.join(ROOT, "rust-raytracing_amd", "librtx_hip.so"))
+    lab = ki.kernel_names(os.path.join(ROOT, "rust-raytracing_amd", "librtx_hip_lab.so"))
+    assert 10 <= len(prod) <= 25, prod
+    assert set(prod) <= set(lab) and len(lab) > len(prod) + 20
+    for experiment in ("trace_sph_pool_kernel", "trace_sph_pair_kernel", "sph_sort_", "trace_bvh_spheres_pool_kernel", "trace_bvh_kernel",
+                       "trace_bvh_regroup_kernel", "wf_trace_beam_kernel", "wf_trace_kernel", "wf_trace_spheres_kernel"):
+        assert not any(k.startswith(experiment) for k in prod), experiment
+        assert any(k.startswith(experiment) for k in lab), experiment
+    for shipped in ("trace_sph_packet_kernel", "trace_bvh_spheres_kernel<false, 2, 2>", "trace_bvh_spheres_kernel<false, 0, 2>",
+                    "wf_trace_packet_kernel<1>", "trace_bvh_mesh_kernel<false, 2, true>", "trace_exact_kernel", "resolve_kernel"):
+        assert shipped in prod, shipped
+    # no "wrong images" timing branches in the product sources any more
+    for f in os.listdir(os.path.join(ROOT, "rust-raytracing_amd", "csrc")):
+        assert "RTX_SPK_LAB" not in open(os.path.join(ROOT, "rust-raytracing_amd", "csrc", f)).read(), f
 
 
 def test_struct_layouts_match_the_header(rtx, tmp_path):
@@ -123,6 +151,7 @@ def test_enum_constants_match_the_header(rtx, tmp_path):
     hdr = open(os.path.join(ROOT, "include", "rtx_hip.h")).read()
     names = sorted(set(re.findall(r"\b(RTX_(?:KERNEL|TUNE|ERR)_[A-Z0-9_]+|RTX_OK)\b\s*=", hdr)))
     assert len(names) > 25
+    names += ["RTX_TUNE_LAB_MASK", "RTX_TUNE_KNOWN_MASK"]           # (macros over the enumerators)
     src = tmp_path / "enums.c"
     src.write_text('#include <stdio.h>\n#include "rtx_hip.h"\nint main(void){\n' +
                    "".join('printf("%s %%lld\\n", (long long)%s);\n' % (n, n) for n in names) + "return 0;}\n")

@@ -32,7 +32,12 @@ def gpu(rtx):
 
 
 def _kernels(rtx):
-    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT]
+    """Every kernel id through the product library (librtx_hip.so: one tree-kernel family per kind of tree, whichever tree id is
+    asked for) and the three tree ids through the lab library (librtx_hip_lab.so: one family per id -- round 1's lock-step and
+    regrouping kernels, the pool kernel, the all-levels wavefront forms).  Same bits everywhere."""
+    L = rtx.LabKernel
+    return [rtx.RTX_KERNEL_EXACT, rtx.RTX_KERNEL_MIXED, rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT,
+            L(rtx.RTX_KERNEL_BVH), L(rtx.RTX_KERNEL_BVH_REGROUP), L(rtx.RTX_KERNEL_WAVEFRONT)]
 
 
 # ---- device arithmetic ---------------------------------------------------------------------------
@@ -230,13 +235,15 @@ def test_bvh_triangle_footprint_tree_is_bit_identical_to_exact_kernel(gpu, n_tri
     objs = scenes.random_triangles(n_tris, 2)
     cam = gpu.Camera(*scenes.CAMERA)
     out = {}
-    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_AUTO):
+    for kern in (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_AUTO, gpu.LabKernel(gpu.RTX_KERNEL_BVH)):
         hnd = gpu.Scene.from_packed(gpu.Config(rays_per_pixel=spp, kernel=kern), cam, objs).upload(0)
         buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-        out[kern] = (buf.cpu().numpy(), st.segments, st.exact_tests, st.kernel)
+        out[repr(kern) if getattr(kern, "lab", False) else kern] = (buf.cpu().numpy(), st.segments, st.exact_tests, st.kernel)
         hnd.close()
     a, b, c = out[gpu.RTX_KERNEL_EXACT], out[gpu.RTX_KERNEL_BVH], out[gpu.RTX_KERNEL_AUTO]
+    lock = out["lab:%d" % gpu.RTX_KERNEL_BVH]                          # round 1's lock-step kernel (librtx_hip_lab.so)
+    assert lock[3] == gpu.RTX_KERNEL_BVH and np.array_equal(a[0], lock[0]) and a[1] == lock[1]
     assert a[0].mean() > 0.01 and np.isfinite(a[0]).all()
     assert np.array_equal(a[0], b[0]) and a[1] == b[1]
     g = out[gpu.RTX_KERNEL_BVH_REGROUP]
@@ -283,9 +290,9 @@ def test_axis_aligned_mesh_stays_inside_the_tree(gpu, oracle):
         ref_b = oracle_render(oracle, objs, w, h, cam=cam, rays_per_pixel=spp, seed=42)
         lit += ref_l.mean() > 0.01
         for ob, ref, exact_everywhere in ((lights, ref_l, True), (objs, ref_b, False)):
-            imgs = {kern: run(ob, cam, kern) for kern in [gpu.RTX_KERNEL_AUTO] + _kernels(gpu)}
-            assert imgs[gpu.RTX_KERNEL_AUTO][2] == gpu.RTX_KERNEL_BVH_REGROUP   # the tree holds the mesh: no fallback to the sweep
-            ex = imgs[gpu.RTX_KERNEL_EXACT]
+            imgs = {repr(kern): run(ob, cam, kern) for kern in [gpu.RTX_KERNEL_AUTO] + _kernels(gpu)}
+            assert imgs[repr(gpu.RTX_KERNEL_AUTO)][2] == gpu.RTX_KERNEL_BVH_REGROUP   # the tree holds the mesh: no fallback to the sweep
+            ex = imgs[repr(gpu.RTX_KERNEL_EXACT)]
             for kern in imgs:
                 assert np.array_equal(imgs[kern][0], ex[0]) and imgs[kern][1] == ex[1], (cam, kern)
             bad = int((np.abs(ex[0] - ref).max(axis=2) > ATOL).sum())
@@ -324,19 +331,25 @@ def test_spheres_kernel_paths(gpu, oracle):
         # frames -- stage 1 as one packet walk per 8x8 tile (trace_sph_packet_kernel) and per lane --, so that every edge
         # case below also crosses the packets, the survivors' queue and the queue-fed stage 2
         out = []
-        for kern, tune in ((gpu.RTX_KERNEL_BVH, 0), (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE),
-                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS),
-                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR),
-                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_CUT),
-                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES),
-                           (gpu.RTX_KERNEL_BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL | gpu.RTX_TUNE_NO_QNODES),
-                           (gpu.RTX_KERNEL_BVH_REGROUP, 0), (gpu.RTX_KERNEL_WAVEFRONT, 0), (gpu.RTX_KERNEL_EXACT, 0)):
+        # (a lab tuning bit, or a LabKernel id, renders through librtx_hip_lab.so; in the product library the three tree ids all
+        #  run the sphere kernels on this tree)
+        L, BVH = gpu.LabKernel, gpu.RTX_KERNEL_BVH
+        for kern, tune, ran in ((BVH, 0, BVH), (BVH, gpu.RTX_TUNE_TWO_STAGE, BVH),
+                                (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_CUT, BVH),
+                                (gpu.RTX_KERNEL_BVH_REGROUP, 0, BVH), (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_TWO_STAGE, BVH),
+                                (L(BVH), 0, BVH), (L(BVH), gpu.RTX_TUNE_TWO_STAGE, BVH),
+                                (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS, BVH),
+                                (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR, BVH),
+                                (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES, BVH),
+                                (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL | gpu.RTX_TUNE_NO_QNODES, BVH),
+                                (L(gpu.RTX_KERNEL_BVH_REGROUP), 0, gpu.RTX_KERNEL_BVH_REGROUP),
+                                (L(gpu.RTX_KERNEL_WAVEFRONT), 0, gpu.RTX_KERNEL_WAVEFRONT), (gpu.RTX_KERNEL_EXACT, 0, gpu.RTX_KERNEL_EXACT)):
             hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, tuning=tune, **cfg).upload(0)
             hnd.set_scratch_limit(scratch)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
             hnd.close()
-            assert st.kernel == kern
+            assert st.kernel == ran, (kern, tune, st.kernel)
             out.append((buf.cpu().numpy(), st.segments, st.exact_tests))
         for o in out[:-1]:
             assert np.array_equal(o[0], out[-1][0]) and o[1] == out[-1][1]
@@ -419,7 +432,10 @@ def test_mesh_kernel_paths(gpu, oracle):
         out = []
         # RTX_KERNEL_WAVEFRONT twice: every level in the wavefront form / the megakernel from level 1 on (the default)
         # and with level 0 as beams (the lanes across nodes) instead of packets (one node per step)
-        for kern, tune in ((gpu.RTX_KERNEL_BVH_REGROUP, 0), (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_WF_PURE),
+        # (WF_PURE and BEAMS are lab bits: those two render through librtx_hip_lab.so, as does LabKernel(BVH) = round 1's lock-step kernel;
+        #  RTX_KERNEL_BVH in the product library runs the mesh kernel on a tree that holds triangles)
+        for kern, tune in ((gpu.RTX_KERNEL_BVH_REGROUP, 0), (gpu.RTX_KERNEL_BVH, 0), (gpu.LabKernel(gpu.RTX_KERNEL_BVH), 0),
+                           (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_WF_PURE),
                            (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_BEAMS), (gpu.RTX_KERNEL_WAVEFRONT, 0), (gpu.RTX_KERNEL_EXACT, 0)):
             hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=42, tuning=tune, **cfg).upload(0)
             hnd.set_scratch_limit(scratch)
@@ -574,11 +590,33 @@ def test_ab_knobs_keep_the_bits(gpu):
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_SORT_SURVIVORS,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR | gpu.RTX_TUNE_NO_QNODES, gpu.RTX_TUNE_PK_LDS_STACK, gpu.RTX_TUNE_BEAMS, gpu.RTX_TUNE_BEAMS | gpu.RTX_TUNE_PK_LDS_STACK, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_CUT, gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_NO_CUT,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_INLINE_LEAVES | gpu.RTX_TUNE_NO_CUT]
+    # a knob with a RTX_TUNE_LAB_MASK bit renders through librtx_hip_lab.so (the product library refuses it, below); the others
+    # through the product library and, as LabKernel ids, through the lab library's kernel family of each id
+    L = gpu.LabKernel
     for tune in knobs:
         for name, o in (("mesh", mesh), ("balls", balls), ("joint", joint)):
-            for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT):
+            for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_WAVEFRONT, L(gpu.RTX_KERNEL_BVH),
+                         L(gpu.RTX_KERNEL_BVH_REGROUP), L(gpu.RTX_KERNEL_WAVEFRONT)):
+                if (tune & gpu.abi.RTX_TUNE_LAB_MASK) and getattr(kern, "lab", False):
+                    continue                                   # (the plain id already went to the lab library)
                 img, segs = render(o, kern, tune)
                 assert np.array_equal(img, ref[name][0]) and segs == ref[name][1], (tune, name, kern)
+    # the product library refuses what it does not hold: every lab bit, and bits the header does not name
+    from rust_raytracing_amd import abi
+    import ctypes as C
+    prod = abi.load_library(False)
+    assert prod.rtx_lab_build() == 0 and abi.load_library(True).rtx_lab_build() == 1
+    hnd = hip_scene(gpu, balls, cam=scenes.CAMERA, rays_per_pixel=1).upload(0)
+    assert not hnd.lab
+    for bit in range(32):
+        tune = 1 << bit
+        cfgc = gpu.Config(rays_per_pixel=1, tuning=tune).to_c()
+        rc = prod.rtx_scene_set_config(hnd._h, C.byref(cfgc))
+        want = abi.RTX_ERR_UNSUPPORTED if (tune & abi.RTX_TUNE_LAB_MASK) or not (tune & abi.RTX_TUNE_KNOWN_MASK) else abi.RTX_OK
+        assert rc == want, (bit, rc)
+        if rc:
+            assert b"tuning" in prod.rtx_last_error()
+    hnd.close()
 
 
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):
@@ -1043,15 +1081,20 @@ def test_c3_full_size_against_the_oracle(gpu, oracle):
     assert np.array_equal(a, buf.cpu().numpy())
     assert st.kernel == gpu.RTX_KERNEL_WAVEFRONT
     assert st.primary_rays == w * h * spp and w * h * spp <= st.segments <= 11 * w * h * spp
+    # the product library: both other tree ids run the mesh kernel alone on this tree
     for kern in (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_BVH_REGROUP):
         hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=kern))
         buf.zero_()
         st2 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-        assert st2.kernel == kern and np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
-    hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=gpu.RTX_KERNEL_WAVEFRONT, tuning=gpu.RTX_TUNE_WF_PURE))   # every level in the wavefront form
-    buf.zero_()
-    st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-    assert st3.kernel == gpu.RTX_KERNEL_WAVEFRONT and np.array_equal(a, buf.cpu().numpy()) and st3.segments == st.segments
+        assert st2.kernel == gpu.RTX_KERNEL_BVH_REGROUP and np.array_equal(a, buf.cpu().numpy()) and st2.segments == st.segments
+    hnd.close()
+    # the lab library: round 1's lock-step kernel, and every level in the wavefront form
+    hnd = sc.upload(0, lab=True)
+    for kern, tune in ((gpu.RTX_KERNEL_BVH, 0), (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_WF_PURE)):
+        hnd.set_config(gpu.Config(rays_per_pixel=spp, seed=42, kernel=kern, tuning=tune))
+        buf.zero_()
+        st3 = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        assert st3.kernel == kern and np.array_equal(a, buf.cpu().numpy()) and st3.segments == st.segments
     hnd.close()
     xs, ys = _scattered_pixels(a, 200, 100, seed=11)
     assert len(xs) >= 256

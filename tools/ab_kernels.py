@@ -1,6 +1,7 @@
 """Variants against each other on a BASELINE config (same box, same process): time, rates, counters and bit equality of the frames.
     tools/ab_kernels.py CONFIG SPP SPEC [SPEC ...] [band]
-        SPEC = KERNEL[:TUNING]   KERNEL = RTX_KERNEL_* id, TUNING = RtxConfig.tuning bits (decimal or 0x..)
+        SPEC = [L]KERNEL[:TUNING]   KERNEL = RTX_KERNEL_* id (L4: the lab library's family of id 4), TUNING = RtxConfig.tuning bits
+                                    (decimal or 0x..; a RTX_TUNE_LAB_MASK bit renders through librtx_hip_lab.so)
         e.g.  C2 64 4 4:8 4:32      (two stages with packets | stage 1 per lane | one stage)
               C3 8 5 6   |   C5 4 5 6 band
     W / H override the frame size, MAXB max_bounces, SCENE=axis:N[:mixed] the scene, BLOCK the row block of the band;
@@ -30,7 +31,7 @@ dev = torch.device("cuda", 0)
 out = {}
 for spec in specs:
     k, _, t = spec.partition(":")
-    k, t = int(k), int(t, 0) if t else 0
+    k, t = (rtx.LabKernel(int(k[1:])) if k.startswith("L") else int(k)), int(t, 0) if t else 0
     hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=scenes.RENDER_SEED, kernel=k, tuning=t, max_bounces=int(os.environ.get("MAXB", 10)), non_focal_offset=float(os.environ.get("NFO", 0.1))), rtx.Camera(*scenes.CAMERA), objs).upload(0)
     band = part.alloc_band(w, dev)
     part.render(hnd, w, band)

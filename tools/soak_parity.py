@@ -29,13 +29,14 @@ def run(name, objs, w, h, spp, kernels):
             hnd = rtx.Scene.from_packed(rtx.Config(rays_per_pixel=spp, seed=SEED_BASE + ci, kernel=kern), rtx.Camera(*cam), objs).upload(0)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
-            out[kern] = (buf.cpu().numpy(), st.segments)
+            out[repr(kern)] = (buf.cpu().numpy(), st.segments)
             hnd.close()
-        ref = out[rtx.RTX_KERNEL_EXACT]
+        ref = out[repr(rtx.RTX_KERNEL_EXACT)]
         for kern in kernels:
-            same = np.array_equal(ref[0], out[kern][0], equal_nan=True) and ref[1] == out[kern][1]
+            got = out[repr(kern)]
+            same = np.array_equal(ref[0], got[0], equal_nan=True) and ref[1] == got[1]
             if not same:
-                print("MISMATCH", name, "camera", ci, "kernel", kern, "max |d|", float(np.nanmax(np.abs(ref[0] - out[kern][0]))))
+                print("MISMATCH", name, "camera", ci, "kernel", kern, "max |d|", float(np.nanmax(np.abs(ref[0] - got[0]))))
                 sys.exit(1)
         total += ref[1]
         print(name, "camera", ci, "segments", ref[1], "mean %.6f" % float(np.nanmean(ref[0])), "identical:", kernels, flush=True)
@@ -44,7 +45,10 @@ def run(name, objs, w, h, spp, kernels):
 
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-    K = [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT, rtx.RTX_KERNEL_MIXED]
+    # the product library's kernels under each tree id and the LDS sweep; LAB=1 adds the lab library's kernel family of each id
+    L = rtx.LabKernel
+    LABK = [L(rtx.RTX_KERNEL_BVH), L(rtx.RTX_KERNEL_BVH_REGROUP), L(rtx.RTX_KERNEL_WAVEFRONT)] if os.environ.get("LAB") else []
+    K = [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT, rtx.RTX_KERNEL_MIXED] + LABK
     n = run("C2 10k spheres", scenes.random_spheres(10000, 1), int(1920 * scale), int(1080 * scale), 1, K)
     n += run("C3 100k triangles", scenes.random_triangles(100000, 2), int(960 * scale), int(540 * scale), 1, K)
     n += run("mixed 3k spheres + 30k triangles + 2 planes",
@@ -55,5 +59,5 @@ if __name__ == "__main__":
              np.concatenate([aam, scenes.random_spheres(2000, 13)]), int(960 * scale), int(540 * scale), 1, K)
     if "c5" in sys.argv[2:]:                      # 1M triangles: the exhaustive kernel needs ~10 s per camera at this size
         n += run("C5 1M triangles", scenes.random_triangles(1000000, 3, box=2.0), int(480 * scale), int(270 * scale), 1,
-                 [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT])
+                 [rtx.RTX_KERNEL_BVH, rtx.RTX_KERNEL_BVH_REGROUP, rtx.RTX_KERNEL_WAVEFRONT] + LABK)
     print("soak ok:", n, "segments compared bit for bit")
