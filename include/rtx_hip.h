@@ -253,7 +253,10 @@ int32_t rtx_scene_set_config(RtxSceneHandle scene, const RtxConfig *config);
 
 /* Upper bound of the per-render scratch this handle allocates on its device (sample records, ray queues), in bytes;
  * 0 = the default (24 GiB, never more than 3/4 of the memory free at render time).  A frame that needs more is traced in
- * sample batches -- same bits (the fold continues across batches).  For several handles, ranks or frameworks sharing a GPU. */
+ * sample batches -- same bits (the fold continues across batches).  For several handles, ranks or frameworks sharing a GPU.
+ * What a launch allocates whatever its batch (a queue chunk per resident wave, counters, stack columns: 0.15-0.3 GB on a
+ * 256-CU part) is taken off the limit before the batch is sized.  The floor is ONE sample of the band per launch: a limit
+ * below that size is exceeded by that one sample's records + the fixed part (a frame cannot be cut finer). */
 int32_t rtx_scene_set_scratch_limit(RtxSceneHandle scene, uint64_t bytes);
 
 /* Scene::add_object (scene.rs:126-128) on an uploaded scene: the objects are appended in order (they get the next scene

@@ -703,6 +703,16 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
     RTX_HIP_CHECK(hipSetDevice(h->device));
     if (int32_t rc = check_watchdog(h, false)) return rc;
     if (int32_t rc = adopt_stream(h, stream)) return rc;
+    // From here on work may be enqueued on `stream`, and last_stream already names it: whatever way this call leaves -- a failed
+    // HIP call after some launches, the watchdog return, the empty-scene answer -- the event a later call on ANOTHER stream waits
+    // for (adopt_stream) is recorded behind everything enqueued so far, so that call never reuses the handle's scratch early.
+    struct DoneGuard {
+        RtxSceneHandle_ *h; hipStream_t stream;
+        ~DoneGuard() {
+            if (hipEventRecord(h->ev_done, stream) == hipSuccess) h->have_done = true;
+            else { (void)hipGetLastError(); (void)hipDeviceSynchronize(); h->have_done = false; }   // (no event: drain instead)
+        }
+    } done_guard{h, stream};
 
     const uint32_t npix = n_rows * width;
     const uint64_t spp = h->cfg.rays_per_pixel;
@@ -785,7 +795,14 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
             const size_t avail = (free_b + mine) / 4 * 3;
             if (cap_bytes > avail) cap_bytes = avail;
         } else (void)hipGetLastError();
-        const uint64_t fit = cap_bytes / (per_sample64 * per_ray);
+        // what a launch allocates whatever its batch -- the survivors' queue's chunk per resident wave and counters, the
+        // wavefront form's level counters and overflow list, the HBM stack columns -- comes off the cap first; the floor is ONE
+        // sample per launch (a frame cannot be cut finer), which a limit below that size gets with the overhead on top
+        const uint64_t fixed = (sph2 ? (uint64_t)bvh_spheres_queue_bytes(0, h->n_cus) + bvh_spheres_spill_bytes(h->sv, h->n_cus) : 0) +
+                               (kernel == RTX_KERNEL_WAVEFRONT ? (uint64_t)wavefront_state_bytes(0, 1) + wavefront_spill_bytes(h->sv, h->n_cus) : 0) +
+                               (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY ? (uint64_t)mixed_state_bytes(h->n_cus) : 0);
+        const uint64_t room = cap_bytes > fixed ? cap_bytes - fixed : 0;
+        const uint64_t fit = room / (per_sample64 * per_ray);
         const uint64_t fit32 = 0xFFFFFFF0ull / per_sample64;
         if (batch > fit) batch = fit ? fit : 1;
         if (batch > fit32) batch = fit32;
@@ -1000,8 +1017,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         RTX_HIP_CHECK(hipEventRecord(h->ev_watchdog, stream));
         h->watchdog_pending = true;
     }
-    RTX_HIP_CHECK(hipEventRecord(h->ev_done, stream));      // what a later call on another stream waits for (adopt_stream)
-    h->have_done = true;
+    // (ev_done -- what a later call on another stream waits for, adopt_stream -- is recorded by done_guard on every way out)
     if (stats) {
         RTX_HIP_CHECK(hipStreamSynchronize(stream));
         Counters host[kCounterShards];

@@ -56,6 +56,43 @@ def test_device_sin_cos_within_one_ulp_of_libm(gpu):
         assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref)))
 
 
+def test_writelane_and_f64_minmax_kats(gpu):
+    """Two toolchain / mode assumptions of the walks, checked on the device (rtx_debug_math ops 6-8, rtx_traverse.h):
+    * rtx_writelane binds llvm.amdgcn.writelane.i32 by name (this clang has no builtin): lane L of every wave takes the value,
+      every other lane keeps its own;
+    * the child sort orders (key, link) pairs with v_min_f64 / v_max_f64 on raw bit patterns: a key of +0.0 makes the pair an
+      f64 DENORMAL whose payload is the link -- it must come back bit for bit (denormals preserved), as must patterns with a
+      +inf key; a flushed pair would send a walk to node 0 for ever."""
+    n = 1024
+    a = np.arange(n, dtype=np.float64) + 7.0
+    for lane in (0, 1, 31, 32, 63):
+        b = np.zeros(n)
+        b[0], b[1] = -123456.0, float(lane)
+        got = gpu.debug_math(6, a, b)
+        want = a.copy()
+        want[lane::64] = -123456.0
+        assert np.array_equal(got, want), lane
+    rng = np.random.default_rng(3)
+    keys = np.concatenate([np.zeros(300, np.float32), rng.uniform(0, 1e3, 300).astype(np.float32), np.full(100, np.inf, np.float32),
+                           rng.uniform(0, 1e-38, 100).astype(np.float32), -rng.uniform(0, 1e-3, 224).astype(np.float32)])
+    keys[-1] = -0.0
+    links = rng.integers(0, 1 << 32, size=(2, n), dtype=np.uint64)
+    pa = (keys[rng.permutation(n)].view(np.uint32).astype(np.uint64) << 32) | links[0]
+    pb = (keys[rng.permutation(n)].view(np.uint32).astype(np.uint64) << 32) | links[1]
+    lo = gpu.debug_math(7, pa.view(np.float64), pb.view(np.float64)).view(np.uint64)
+    hi = gpu.debug_math(8, pa.view(np.float64), pb.view(np.float64)).view(np.uint64)
+    # as f64 values (no NaN among them): sign-magnitude order of the 64-bit patterns
+    def order(u):
+        s = u.astype(np.int64)
+        return np.where(s < 0, ~s ^ np.int64(-(2 ** 63)), s)
+    oa, ob = order(pa), order(pb)
+    want_lo, want_hi = np.where(oa <= ob, pa, pb), np.where(oa <= ob, pb, pa)
+    eq = oa == ob
+    assert np.array_equal(lo[~eq], want_lo[~eq]) and np.array_equal(hi[~eq], want_hi[~eq])
+    assert np.all((lo[eq] == pa[eq]) | (lo[eq] == pb[eq]))
+    assert int((pa >> 32 == 0).sum()) > 100                     # the denormal pairs (key +0.0) were among them
+
+
 # ---- golden fixtures and seeded scenes: HIP == oracle ------------------------------------------------
 @pytest.mark.parametrize("name", ["c1_three_spheres_32x32", "spheres200_48x27", "mixed_40x24", "tris300_32x18"])
 def test_hip_matches_golden(gpu, oracle, name):
@@ -132,6 +169,28 @@ def test_closed_form_values_pin_the_device_path(gpu):
                 objs, tcam, cfg, want = cf.triangle_distance_bracket(dt, direction, dist, delta)
                 img = hip_render(gpu, objs, 1, 1, cam=tcam, kernel=kern, **cfg)
                 assert tuple(img.ravel()) == tuple(want), (kern, direction, delta)
+
+
+def test_bounce_direction_is_pinned_without_the_oracle(gpu):
+    """random_bounce_dir / random_direction (scene.rs:279-292, vector.rs:36-45) on the device against values the reference's TEXT
+    determines (tests/closed_form.py), no oracle in the loop, for every kernel: (i) roughness 0 -- the bounced ray is the mirror
+    direction d - (n * 2) * (d . n), flipped to the normal's side: a light centred on it is met (pixel = mirror emission + mirror
+    base * light emission, exactly), a light displaced by more than its radius is not; planes, a sphere, a triangle seen from
+    behind.  (ii) roughness 1 -- uniform on the hemisphere: of 2^22 bounced rays the share that meets a light subtending a cone
+    of half angle asin(0.6) is 1 - sqrt(1 - 0.36) = 0.2 within 5 sigma (cosine-weighted would be 0.36, no flip 0.1)."""
+    import closed_form as cf
+    dt = gpu.OBJECT_DTYPE
+    for name, objs, cam, cfg, want in cf.mirror_cases(dt):
+        for kern in _kernels(gpu):
+            img = hip_render(gpu, objs, 1, 1, cam=cam, kernel=kern, **cfg)
+            assert tuple(img.ravel()) == tuple(want), (name, kern)
+    objs, cam, cfg, p, value = cf.hemisphere_light(dt)
+    for kern in _kernels(gpu):
+        for tune in ((0, gpu.RTX_TUNE_TWO_STAGE) if int(kern) == gpu.RTX_KERNEL_BVH else (0,)):
+            means = [hip_render(gpu, objs, 64, 64, cam=cam, kernel=kern, rays_per_pixel=256, seed=seed, tuning=tune, **cfg).mean(axis=(0, 1))
+                     for seed in (21, 22, 23, 24)]
+            err, bound = cf.hemisphere_check(float(np.mean(means)), 4 * 64 * 64 * 256, p, value)
+            assert err <= bound, (kern, tune, err, bound)
 
 
 def test_closed_box_at_two_stage_size_every_ray_survives(gpu):
@@ -617,6 +676,31 @@ def test_ab_knobs_keep_the_bits(gpu):
         if rc:
             assert b"tuning" in prod.rtx_last_error()
     hnd.close()
+
+
+def test_product_fallback_for_a_sphere_tree_without_64_byte_nodes(gpu):
+    """The product library holds the sphere kernels in their 64-byte-node instances only.  A sphere tree whose nodes have no such
+    form (coordinates beyond the quantisation's exact range: |origin / step| + 256 >= 2^24) renders with the LDS sweep under every
+    kernel id, with the exhaustive kernel's bits; the lab library walks its 128-byte nodes.  (A pure footprint tree always has its
+    64-byte form when the tree is built at all -- rtx_api.hip would let it walk as a joint tree otherwise.)"""
+    import torch
+    from rust_raytracing_amd import scenes
+    balls = scenes.light_every(scenes.compact(scenes.random_spheres(300, 5)))
+    balls["geom"][:, :3] += (3.0e8, 0.0, 0.0)
+    cam = ((3.0e8 - 5.0, 0.0, 0.0), (1.0, 0.0, 0.0), 1.2)
+    st = gpu.debug_host_scene(gpu.Scene.from_packed(gpu.Config(), gpu.Camera(*cam), balls))
+    assert st["flags"] & 1 and not st["flags"] & 16 and st["wide_nodes"] > 50
+    ref = hip_render(gpu, balls, 48, 32, cam=cam, kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=2, seed=4)
+    assert ref.mean() > 0.01
+    L = gpu.LabKernel
+    for kern, ran in ((gpu.RTX_KERNEL_AUTO, gpu.RTX_KERNEL_MIXED), (gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_MIXED),
+                      (gpu.RTX_KERNEL_BVH_REGROUP, gpu.RTX_KERNEL_MIXED), (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_KERNEL_MIXED),
+                      (L(gpu.RTX_KERNEL_BVH), gpu.RTX_KERNEL_BVH), (L(gpu.RTX_KERNEL_AUTO), gpu.RTX_KERNEL_BVH)):
+        hnd = hip_scene(gpu, balls, cam=cam, kernel=kern, rays_per_pixel=2, seed=4, tuning=gpu.RTX_TUNE_TWO_STAGE).upload(0)
+        buf = torch.zeros((32, 48, 3), dtype=torch.float64, device="cuda:0")
+        stt = hnd.render_rows(48, 32, 0, 1, 32, buf.data_ptr())
+        hnd.close()
+        assert stt.kernel == ran and np.array_equal(buf.cpu().numpy(), ref), (kern, stt.kernel)
 
 
 def test_bvh_joint_tree_with_out_of_range_and_axis_parallel_rays(gpu, oracle):

@@ -264,6 +264,23 @@ def test_closed_form_values_pin_the_oracle(oracle, rtx):
             assert tuple(img.ravel()) == tuple(want), (direction, delta)
 
 
+def test_bounce_direction_is_pinned_without_the_kernels(oracle, rtx):
+    """random_bounce_dir / random_direction (scene.rs:279-292, vector.rs:36-45) against values the reference's text determines
+    (tests/closed_form.py): roughness 0 -> the mirror direction exactly enough to meet / miss a light (5 mirrors x 2), roughness 1
+    -> uniform on the hemisphere: the share of 2^22 bounced rays that meet a light of known solid angle."""
+    import closed_form as cf
+    dt = rtx.OBJECT_DTYPE
+    for name, objs, cam, cfg, want in cf.mirror_cases(dt):
+        img = oracle_render(oracle, objs, 1, 1, cam=cam, **cfg)
+        assert tuple(img.ravel()) == tuple(want), name
+    objs, cam, cfg, p, value = cf.hemisphere_light(dt)
+    assert abs(p - 0.2) < 1e-12
+    means = [oracle_render(oracle, objs, 32, 32, cam=cam, rays_per_pixel=1024, seed=seed, **cfg).mean(axis=(0, 1)) for seed in (11, 12, 13, 14)]
+    err, bound = cf.hemisphere_check(float(np.mean(means)), 4 * 32 * 32 * 1024 * 3 // 3, p, value)
+    assert err <= bound, (err, bound)
+    assert bound < 0.01 * p * value                     # the test can tell 0.2 from the nearest wrong answer (0.1, 0.36) by far
+
+
 @pytest.mark.parametrize("name", ["c1_three_spheres_32x32", "spheres200_48x27", "mixed_40x24", "tris300_32x18"])
 def test_oracle_reproduces_golden(oracle, name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
