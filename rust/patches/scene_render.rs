@@ -1,15 +1,18 @@
 // patches/scene_render.rs -- new bodies of Scene::render / Scene::render_to_image (src/raytracing/scene.rs:144-178).
 // UNCOMPILED.  One FFI call each; everything below them (render_pixel .. random_bounce_dir, scene.rs:194-292) runs in
 // hand-written HIP on the MI355X.  Signatures, [y][x] orientation and the panic-on-failure behaviour are the reference's.
-use crate::raytracing::hip;
+use crate::raytracing::hip::{self, RenderOptions, SceneHipExt};
 use crate::raytracing::object::Primitive;
 
-impl Scene {
-    pub fn render(&self, width: usize, height: usize) -> Vec<Vec<Vector3>> {
+// The per-call form: seed and device list are arguments, nothing process-wide (hip.rs).  `scene.render_seeded(w, h, 7)`,
+// `scene.render_on(w, h, &[0, 1, 2, 3])` come with the trait.
+impl SceneHipExt for Scene {
+    type Pixel = Vector3;
+    fn render_with(&self, width: usize, height: usize, opts: &RenderOptions) -> Vec<Vec<Vector3>> {
         let packed = self.pack(); // scene order is kept: it decides ties (scene.rs:250)
-        let sc = self.to_c(&packed);
+        let sc = self.to_c(&packed, opts.key());
         let mut flat = vec![0f64; width * height * 3];
-        let devices = hip::render_devices();
+        let devices = &opts.devices;
         let rc = unsafe {
             if devices.is_empty() {
                 hip::rtx_render(&sc, width as u32, height as u32, flat.as_mut_ptr())
@@ -22,13 +25,25 @@ impl Scene {
             .map(|row| row.chunks(3).map(|c| Vector3::new(c[0], c[1], c[2])).collect())
             .collect()
     }
+}
+
+impl Scene {
+    /// The reference's signature (scene.rs:144): this thread's defaults (hip::with_render_defaults), else a fresh key on device 0.
+    pub fn render(&self, width: usize, height: usize) -> Vec<Vec<Vector3>> {
+        self.render_with(width, height, &hip::render_defaults())
+    }
 
     #[cfg(feature = "images")]
     pub fn render_to_image(&self, width: usize, height: usize) -> ImageBuffer<Rgb<u8>, Vec<u8>> {
+        self.render_to_image_with(width, height, &hip::render_defaults())
+    }
+
+    #[cfg(feature = "images")]
+    pub fn render_to_image_with(&self, width: usize, height: usize, opts: &RenderOptions) -> ImageBuffer<Rgb<u8>, Vec<u8>> {
         let packed = self.pack();
-        let sc = self.to_c(&packed);
+        let sc = self.to_c(&packed, opts.key());
         let mut buf = vec![0u8; width * height * 3];
-        let devices = hip::render_devices();
+        let devices = &opts.devices;
         let rc = unsafe {
             if devices.is_empty() {
                 hip::rtx_render_to_image(&sc, width as u32, height as u32, buf.as_mut_ptr())
@@ -61,7 +76,7 @@ impl Scene {
         }).collect()
     }
 
-    fn to_c(&self, packed: &[hip::RtxObject]) -> hip::RtxScene {
+    fn to_c(&self, packed: &[hip::RtxObject], seed: u64) -> hip::RtxScene {
         let c = &self.config;
         let cam = &self.camera;
         let rows = |m: &Mat3x3| [m.x.x, m.x.y, m.x.z, m.y.x, m.y.y, m.y.z, m.z.x, m.z.y, m.z.z]; // mat.rs:11-18: three row vectors
@@ -69,7 +84,7 @@ impl Scene {
             config: hip::RtxConfig {
                 rays_per_pixel: c.rays_per_pixel as u64, max_bounces: c.max_bounces as u64,
                 focal_length: c.focal_length, focal_offset: c.focal_offset, non_focal_offset: c.non_focal_offset,
-                seed: hip::render_seed(), kernel: hip::RTX_KERNEL_AUTO, tuning: 0,
+                seed, kernel: hip::RTX_KERNEL_AUTO, tuning: 0,
             },
             camera: hip::RtxCamera {
                 fov: cam.fov, position: cam.position.into(), direction: cam.get_direction().into(),

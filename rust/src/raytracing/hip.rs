@@ -86,6 +86,7 @@ extern "C" {
     pub fn rtx_version() -> i32;
     pub fn rtx_last_error() -> *const c_char;
     pub fn rtx_device_count() -> i32;
+    pub fn rtx_lab_build() -> i32;
     pub fn rtx_camera_new(position: *const f64, direction: *const f64, fov: f64, out: *mut RtxCamera) -> i32;
     pub fn rtx_render(scene: *const RtxScene, width: u32, height: u32, out_rgb: *mut f64) -> i32;
     pub fn rtx_render_to_image(scene: *const RtxScene, width: u32, height: u32, out_rgb8: *mut u8) -> i32;
@@ -113,31 +114,63 @@ pub fn check(rc: i32) {
 
 // ---- what the device path needs and the reference's types cannot carry -------------------------------------------------
 // `Config` and `Scene` are plain `pub` structs that users build with struct literals (scene.rs:16-28, :78-85), so the shim
-// adds NO field to them.  The two settings the device path adds are process-wide instead, set through these functions:
+// adds NO field to them -- and NO process-wide state either: `Scene::render(&self)` is re-entrant in the reference and may run
+// on several threads at once (clones share the shapes behind Arc<Mutex>, object.rs:9-15), so two scenes must be able to render
+// with different seeds / device lists concurrently.  The two settings the device path adds travel PER CALL:
 //   * the render seed: the reference draws from fastrand's never-seeded thread-local generator on one thread per row
-//     (math/vector.rs:31-38, scene.rs:151) -- every run renders a different image.  Default here: a fresh key per
-//     `render()` call (same behaviour); `set_render_seed(Some(k))` makes renders reproducible (they never were).
-//   * the GPUs a frame is partitioned over (blocks of rows, one gather); default: device 0.
-use std::sync::atomic::{AtomicBool, AtomicU64, Ordering};
-use std::sync::Mutex;
+//     (math/vector.rs:31-38, scene.rs:151) -- every run renders a different image.  `None` keeps that behaviour (a fresh
+//     key per call); `Some(k)` makes a render reproducible (it never was).
+//   * the GPUs a frame is partitioned over (blocks of rows, one gather); empty: device 0.
+// `SceneHipExt` (patches/scene_render.rs implements it for `Scene`) takes them as arguments; the reference's own
+// `Scene::render(&self, w, h)` delegates to it with this THREAD's defaults, which `with_render_defaults` scopes.
+use std::cell::RefCell;
 
-static SEED_FIXED: AtomicBool = AtomicBool::new(false);
-static SEED: AtomicU64 = AtomicU64::new(0);
-static DEVICES: Mutex<Vec<i32>> = Mutex::new(Vec::new());
-
-pub fn set_render_seed(seed: Option<u64>) {
-    if let Some(s) = seed { SEED.store(s, Ordering::Relaxed); }
-    SEED_FIXED.store(seed.is_some(), Ordering::Release);
+#[derive(Clone, Debug, Default)]
+pub struct RenderOptions {
+    pub seed: Option<u64>,
+    pub devices: Vec<i32>,
 }
 
-pub fn render_seed() -> u64 {
-    if SEED_FIXED.load(Ordering::Acquire) { SEED.load(Ordering::Relaxed) } else { fastrand::u64(..) }
+impl RenderOptions {
+    pub fn seeded(seed: u64) -> Self { RenderOptions { seed: Some(seed), devices: Vec::new() } }
+    pub fn on(devices: &[i32]) -> Self { RenderOptions { seed: None, devices: devices.to_vec() } }
+    /// The key of THIS call: the fixed seed, or a fresh one (the reference's "a different image every run").
+    pub fn key(&self) -> u64 { self.seed.unwrap_or_else(|| fastrand::u64(..)) }
 }
 
-pub fn set_render_devices(devices: &[i32]) {
-    *DEVICES.lock().unwrap() = devices.to_vec();
+thread_local! {
+    static DEFAULTS: RefCell<RenderOptions> = RefCell::new(RenderOptions::default());
 }
 
-pub fn render_devices() -> Vec<i32> {
-    DEVICES.lock().unwrap().clone()
+/// What `Scene::render(&self, w, h)` -- the reference's signature, which has no room for options -- uses on this thread.
+pub fn render_defaults() -> RenderOptions {
+    DEFAULTS.with(|d| d.borrow().clone())
+}
+
+/// Runs `f` with `opts` as this thread's defaults and restores the previous ones afterwards (also when `f` panics, as the
+/// reference's render does on failure): `hip::with_render_defaults(RenderOptions::seeded(7), || scene.render(w, h))`.
+pub fn with_render_defaults<R>(opts: RenderOptions, f: impl FnOnce() -> R) -> R {
+    struct Restore(Option<RenderOptions>);
+    impl Drop for Restore {
+        fn drop(&mut self) {
+            if let Some(prev) = self.0.take() { DEFAULTS.with(|d| *d.borrow_mut() = prev); }
+        }
+    }
+    let _restore = Restore(Some(DEFAULTS.with(|d| std::mem::replace(&mut *d.borrow_mut(), opts))));
+    f()
+}
+
+/// The per-call form of the render entry points (implemented for `Scene` in patches/scene_render.rs).
+pub trait SceneHipExt {
+    type Pixel;
+    /// `Scene::render` with everything the device path adds passed explicitly.
+    fn render_with(&self, width: usize, height: usize, opts: &RenderOptions) -> Vec<Vec<Self::Pixel>>;
+    /// A reproducible render: the same seed gives the same image on any partition of the frame.
+    fn render_seeded(&self, width: usize, height: usize, seed: u64) -> Vec<Vec<Self::Pixel>> {
+        self.render_with(width, height, &RenderOptions::seeded(seed))
+    }
+    /// The frame partitioned over `devices` (blocks of 8 rows round-robin, one gather on `devices[0]`).
+    fn render_on(&self, width: usize, height: usize, devices: &[i32]) -> Vec<Vec<Self::Pixel>> {
+        self.render_with(width, height, &RenderOptions::on(devices))
+    }
 }

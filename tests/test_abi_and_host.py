@@ -195,6 +195,20 @@ def test_rust_shim_matches_the_header(tmp_path):
     assert "self.config.seed" not in body and "self.config.devices" not in body
     for f in os.listdir(os.path.join(ROOT, "rust", "patches")):
         assert not re.search(r"pub\s+fn\s+with_\w+\s*\(\s*self\b", open(os.path.join(ROOT, "rust", "patches", f)).read()), f
+    # ... and no process-wide render state: Scene::render(&self) is re-entrant across threads in the reference, so seed
+    # and device list travel per call (SceneHipExt::render_with / render_seeded / render_on); the plain render() reads THREAD-local
+    # defaults.  No `static mut`, no global Mutex / atomic / OnceLock / lazy_static in the shim.
+    for path in [os.path.join(ROOT, "rust", "src", "raytracing", "hip.rs")] + [os.path.join(ROOT, "rust", "patches", f)
+                                                                               for f in os.listdir(os.path.join(ROOT, "rust", "patches"))]:
+        code = re.sub(r"//[^\n]*", "", open(path).read())
+        statics = re.findall(r"^\s*(?:pub\s+)?static\s+(?:mut\s+)?\w+\s*:\s*[^=;]+", code, flags=re.M)
+        outside_tls = [st for st in statics if not re.search(r"thread_local!\s*\{[^}]*" + re.escape(st.strip()), code, flags=re.S)]
+        assert not outside_tls, (path, outside_tls)
+        assert not re.search(r"\bstatic\s+mut\b|lazy_static!|OnceLock|OnceCell<", code), path
+    assert "thread_local!" in rs and "pub trait SceneHipExt" in rs
+    for fn in ("render_with", "render_seeded", "render_on"):
+        assert re.search(r"fn\s+%s\s*\(\s*&self\b" % fn, rs), fn
+    assert "impl SceneHipExt for Scene" in body and "hip::render_defaults()" in body and "set_render_seed" not in rs + body
 
 
 def test_cpp_host_header_compiles(tmp_path):
