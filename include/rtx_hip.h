@@ -142,12 +142,16 @@ enum {
                                         earlier form) instead of being pushed and visited when popped, leaf visits apart from node visits */
     RTX_TUNE_NO_CUT = 1u << 23,      /* sphere trees: every round of a lock-step wave lasts until its longest walk ends (round 2's
                                         form) instead of leaving the last few walkers to continue beside the next segments */
+    RTX_TUNE_STAGE2_SLOTS = 1u << 26, /* sphere trees, two stages: stage 2 over ray slots (trace_sph_slots_kernel: a wave owns ~90 rays, a lane
+                                        whose walk ends takes the next READY one from LDS, the f64 phase runs for 64 finished walks at once;
+                                        round 4's experiment: 12 % fewer instructions, the same time -- LAB_NOTEBOOK R4.3) */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };
 
 #define RTX_TUNE_LAB_MASK (RTX_TUNE_BVH_CLASSIC | RTX_TUNE_NO_QNODES | RTX_TUNE_NO_PACKETS | RTX_TUNE_WF_PURE | RTX_TUNE_PK_LDS_STACK | \
-                           RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR | RTX_TUNE_BEAMS | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_SORT_SURVIVORS)
+                           RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR | RTX_TUNE_BEAMS | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_SORT_SURVIVORS | \
+                           RTX_TUNE_STAGE2_SLOTS)
 #define RTX_TUNE_KNOWN_MASK (RTX_TUNE_LAB_MASK | RTX_TUNE_NO_TILES | RTX_TUNE_ONE_STAGE | RTX_TUNE_TWO_STAGE | RTX_TUNE_BVH_MEDIAN | \
                              (15u << RTX_TUNE_TRI_LEAF_SHIFT) | (127u << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT)
 

@@ -90,7 +90,8 @@ struct RtxSceneHandle_ {
     double *h_tables = nullptr; size_t h_tables_doubles = 0;
     double *state = nullptr;    size_t state_bytes = 0;
     void *wf_state = nullptr;   size_t wf_bytes = 0;       // the wavefront kernels' ray state
-    void *pool = nullptr;       size_t pool_bytes = 0;     // the sphere kernel's stage-2 slots
+    void *pool = nullptr;       size_t pool_bytes = 0;     // (lab) the pool / pair forms of the sphere kernel's stage 2
+    void *slots = nullptr;      size_t slots_bytes = 0;    // the slot records of the sphere kernel's stage 2 (trace_sph_slots_kernel)
     Counters *counters = nullptr;
     unsigned long long *work_counter = nullptr;
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
@@ -186,6 +187,7 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->state) (void)hipFree(h->state);
     if (h->wf_state) (void)hipFree(h->wf_state);
     if (h->pool) (void)hipFree(h->pool);
+    if (h->slots) (void)hipFree(h->slots);
     if (h->counters) (void)hipFree(h->counters);
     if (h->counters_stage1) (void)hipFree(h->counters_stage1);
     if (h->work_counter) (void)hipFree(h->work_counter);
@@ -880,6 +882,15 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
     const bool spheres_two_stage = spheres_kernel && h->cfg.max_bounces > 0 && (tuning & RTX_TUNE_ONE_STAGE) == 0u &&
                                    (batch * per_sample64 >= (1ull << 20) || (tuning & RTX_TUNE_TWO_STAGE) != 0u) &&
                                    bvh_spheres_two_stage_ok(h->sv, tiled);
+#ifdef RTX_LAB
+    const bool stage2_slots = spheres_two_stage && (tuning & RTX_TUNE_STAGE2_SLOTS) != 0u && (h->sv.bvh_flags & 16u) != 0u &&
+                              (tuning & (RTX_TUNE_NO_QNODES | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) == 0u;
+    if (stage2_slots) {
+        if (int32_t rc = grow(&h->slots, &h->slots_bytes, bvh_spheres_slots_bytes(h->n_cus))) return rc;
+    }
+#else
+    const bool stage2_slots = false;
+#endif
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
 #ifdef RTX_LAB
@@ -972,7 +983,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                        ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u) |
                                                            ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u) | ((tuning & RTX_TUNE_STAGE2_PAIR) ? 8u : 0u), stream,
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
-                                                       stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr));
+                                                       stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr,
+                                                       stage2_slots ? h->slots : nullptr));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,

@@ -366,6 +366,7 @@ struct Bvh4Build {
 };
 
 inline float u32_as_f32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+constexpr int kBvhTopLevels = 6;           // collapse_to_bvh4 numbers the nodes of the first kBvhTopLevels + 1 levels breadth-first
 
 inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
 {
@@ -381,14 +382,20 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
         return (double)INFINITY;                                   // a joint over several planes: open it first
     };
     auto flat = [&](uint32_t bin) { return bin < b2.flat.size() && b2.flat[bin] != 0; };     // a node of the (x, y) sub-tree
+    // Node numbering: the top of the tree breadth-first (every node of depth <= kBvhTopLevels + 1 before any deeper one, level by
+    // level), the rest depth-first (a sub-tree's nodes stay together).  The children of a node always get consecutive indices.
+    // A kernel that keeps the nodes every walk passes through close to the lanes (the slot kernel's LDS copy of nodes [0, K)) can
+    // then take any prefix of the array: a prefix is the top of the tree.
     struct Task { uint32_t bin; uint32_t wide; int depth; };
-    std::vector<Task> todo;
+    std::vector<Task> todo, top;
+    size_t top_head = 0;
     out.nodes.emplace_back();
     out.root = flat(0u) ? kBvhFlatNode : 0u;
-    todo.push_back({0u, 0u, 1});
-    while (!todo.empty()) {
-        const Task t = todo.back();
-        todo.pop_back();
+    top.push_back({0u, 0u, 1});
+    while (top_head < top.size() || !todo.empty()) {
+        Task t;
+        if (top_head < top.size()) t = top[top_head++];
+        else { t = todo.back(); todo.pop_back(); }
         out.depth = std::max(out.depth, t.depth);
         uint32_t kids[4];
         int nk = 0;
@@ -418,7 +425,7 @@ inline Bvh4Build collapse_to_bvh4(const BvhBuild &b2)
                 if (count == 0) {                                 // interior child: gets its own wide node
                     link = (uint32_t)out.nodes.size();
                     out.nodes.emplace_back();
-                    todo.push_back({kids[c], link, t.depth + 1});
+                    (t.depth + 1 <= kBvhTopLevels ? top : todo).push_back({kids[c], link, t.depth + 1});
                     if (flat(kids[c])) link |= kBvhFlatNode;
                 }
                 links[c] = link; counts[c] = count;

@@ -722,7 +722,7 @@ uint32_t bvh_spheres_spill_entries(const SceneView &sv)
 size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus)
 {
 #ifdef RTX_LAB
-    const int lds_rows = kPoolStack;                     // (the lab's pool kernel has the shorter LDS stack)
+    const int lds_rows = kSlotStack < kPoolStack ? kSlotStack : kPoolStack;      // (the shortest LDS stack of the kernels that share the columns)
 #else
     const int lds_rows = kSphStack;
 #endif
@@ -768,7 +768,7 @@ bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled)
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot, hipEvent_t stage1_done,
-                                    void *pool_mem)
+                                    void *pool_mem, void *slots_mem)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -844,6 +844,19 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                            spill_entries, sq);
         return hipGetLastError();
     }
+#endif
+#ifdef RTX_LAB
+    if (slots_mem) {                                     // stage 2 over ray slots: the grid is the resident waves, each with its own slots
+        if (!q3) return hipErrorInvalidValue;
+        const uint32_t se = spill ? bvh_spheres_slots_spill_entries(sv) : 0u;
+        if (bvh_spheres_slots_spill_entries(sv) != 0u && !spill) return hipErrorInvalidValue;
+        auto ks = se ? trace_sph_slots_kernel<true> : trace_sph_slots_kernel<false>;
+        hipLaunchKernelGGL(ks, dim3((uint32_t)cap), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, ctrs + 1, q3nodes, la, spill, se, sq,
+                           reinterpret_cast<SlotRec *>(slots_mem));
+        return hipGetLastError();
+    }
+#else
+    (void)slots_mem;
 #endif
     // the queue-fed stage walks per lane over the 64-byte nodes: half the L1 requests per visit
     auto k2 = deep ? trace_bvh_spheres_kernel<true, 2, 2> : trace_bvh_spheres_kernel<false, 2, 2>;

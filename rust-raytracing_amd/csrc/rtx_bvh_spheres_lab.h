@@ -1,5 +1,6 @@
 // rtx_bvh_spheres_lab.h -- the experiments on the sphere path that lost (profiles/LAB_NOTEBOOK.md R3.2, R3.4, R3.7): stage 2 as a
-// wave-local pool of ray slots, stage 2 with two rays per lane, a counting sort of the survivors between the stages.  All of them
+// wave-local pool of ray slots, stage 2 with two rays per lane, a counting sort of the survivors between the stages -- and round 4's
+// stage 2 over ray slots in LDS (R4.3).  All of them
 // render the product's bits.  Compiled only with -DRTX_LAB (librtx_hip_lab.so), included by rtx_bvh_spheres.hip inside namespace
 // rtx, after the product kernels whose types and constants it uses (SphQueue, SphSurvivor, kSphStack, the walks of rtx_traverse.h).
 #pragma once
@@ -715,6 +716,342 @@ __global__ __launch_bounds__(256) void sph_sort_scatter_kernel(const SphQueue sq
             if (key[j] != 0xFFFFFFFFu) so.perm[base[key[j]] + rank[j]] = (uint32_t)i;
         }
         __syncthreads();
+    }
+}
+
+
+// ---- stage 2 over ray slots (round 4, LAB_NOTEBOOK R4.3: built, bit-identical, on par with the lock-step form -- not shipped) ---------
+// The lock-step stage 2 above gives a lane ONE ray for the ray's whole life, so a round of its wave lasts as long as the round's
+// longest walk: node visits run with 37 of 64 lanes, the f64 phase with 49 (LAB_NOTEBOOK R3.12).  Round 3 tried twice to hand a
+// lane another ray the moment its walk ends (R3.4: a pool of slots in device memory, R3.7: two rays per lane); both cut the
+// instructions by a third and lost the time again to memory latency -- every hand-over was a round trip to a 113 MB pool, or cost
+// the registers that hide latency.  What was missing is LDS, and the LDS was there all along: the 30-entry stack holds at most 9
+// entries on C2 (0 of 3.7e7 walks went deeper, 0.6 % beyond 7: R4.2), so 20 KB of every workgroup's 39 KB were never touched.
+//
+// Here a wave owns kSlotN ray slots.  A slot is
+//   READY    set up: the 16 f32 walk parameters (Ray32S + SphereRay) are in the slot's LDS words, waiting for a lane
+//   WALKING  a lane has taken the parameters into registers and walks; the slot's LDS words now hold its candidate queue
+//   DONE     the walk has ended: candidates, best_up and flags in the slot's LDS words, waiting for the f64 phase
+//   FREE     (a DONE slot flagged fresh) no ray: the next f64 phase puts a survivor of stage 1's queue into it
+// * a lane whose walk ends leaves its slot DONE and takes a READY one -- LDS reads only, served for kSlotWait lanes together so
+//   that the hand-over code is not issued for one lane at a time;
+// * when 64 slots are DONE (or the walk starves) the WAVE runs one f64 phase over 64 DONE slots with all lanes -- lane i
+//   serves slot done[i], not the ray it walks: exact tests, ray_hit, the next segment's set-up (-> READY), or the sample store;
+// * the f64 path state of a slot (pos, dir, result, light, RNG key, indices: one 128-byte record) lives in device memory,
+//   read and written once per segment by the f64 phase -- the lock-step kernel moved as much through its scratch spills.
+// The walk is the phased walk of rtx_traverse.h (node visits and leaf visits apart) over the 64-byte nodes, per lane, with the
+// same pruning: same candidates up to the order best_up tightens in, same exact tests, same bits.
+#ifndef RTX_SLOT_N
+#define RTX_SLOT_N 88
+#endif
+#ifndef RTX_SLOT_TOP
+#define RTX_SLOT_TOP 85
+#endif
+#ifndef RTX_SLOT_STACK
+#define RTX_SLOT_STACK 10
+#endif
+#ifndef RTX_SLOT_WAIT
+#define RTX_SLOT_WAIT 12
+#endif
+#ifndef RTX_SLOT_SERVE
+#define RTX_SLOT_SERVE 24
+#endif
+constexpr int kSlotN = RTX_SLOT_N;                    // ray slots per wave
+constexpr int kSlotStack = RTX_SLOT_STACK;            // LDS stack entries per lane (+ the sink row); deeper walks use the HBM column
+constexpr int kSlotWords = 16;                        // LDS words per slot
+constexpr int kSlotTop = RTX_SLOT_TOP;                // nodes [0, kSlotTop) of the tree (its first levels) are copied into LDS, per workgroup
+constexpr uint32_t kSlotWait = RTX_SLOT_WAIT;         // lanes whose walk has ended before they are served together
+constexpr uint32_t kSlotServe = RTX_SLOT_SERVE;       // idle lanes (nothing READY) that trigger an f64 phase before 64 slots are DONE
+constexpr uint32_t kSlotFresh = 1u << 10, kSlotNoWalk = 1u << 9, kSlotOverflow = 1u << 8;
+static_assert(kSlotN >= 64 && kSlotN <= 255 && kSlotN % 4 == 0, "slot ids are bytes; the first f64 phase fills 64 slots");
+struct SlotRec { double4 a, b, c, d; };               // {pos.xyz, dir.x} {dir.yz, result.xy} {result.z, light.xyz} {key, ridx | bounce << 32, -, -}
+static_assert(sizeof(SlotRec) == 128, "one slot record = one 128-byte line");
+
+size_t bvh_spheres_slots_bytes(int n_cus)
+{
+    return (size_t)n_cus * kSphWavesPerSimd * (kBvhThreads / 64) * kSlotN * sizeof(SlotRec) + 256;
+}
+
+uint32_t bvh_spheres_slots_spill_entries(const SceneView &sv)
+{
+    const uint32_t need = 3u * sv.bvh_depth + 2u;
+    return need > (uint32_t)kSlotStack ? need - (uint32_t)kSlotStack : 0u;
+}
+
+template <bool SPILL>
+__global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_slots_kernel(const SceneView *__restrict__ svp,
+                                                                               const RowsView *__restrict__ rvp,
+                                                                               double *__restrict__ samples, Counters *__restrict__ ctr,
+                                                                               unsigned long long *__restrict__ work_counter,
+                                                                               const float4 *__restrict__ qnodes, const LeafArrays la,
+                                                                               uint32_t *__restrict__ spill, uint32_t spill_entries,
+                                                                               const SphQueue sq, SlotRec *__restrict__ pool)
+{
+    constexpr int STACK = kSlotStack;
+    constexpr int WAVES = kBvhThreads >> 6;
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    __shared__ uint32_t lds_stack[STACK + 1][kBvhThreads];                 // + the sink row of the branch-free pushes
+    __shared__ uint32_t lds_slot[WAVES][kSlotWords][kSlotN];              // READY: 0-6 Ray32S, 7-15 SphereRay; WALKING / DONE: 0-3 candidate
+                                                                           // index, 4-7 its t_lo, 8 best_up, 9 qcnt | flags
+    __shared__ uint8_t lds_lists[WAVES][2][kSlotN];                       // per wave: [0] DONE slots (a queue), [1] READY slots (a stack)
+    __shared__ float4 lds_top[kSlotTop > 0 ? 4 * kSlotTop : 4];           // the 64-byte nodes [0, top_n): the top of the tree
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t top_n = kSlotTop > 0 ? (sv.n_bvh_nodes < (uint32_t)kSlotTop ? sv.n_bvh_nodes : (uint32_t)kSlotTop) : 0u;
+    for (uint32_t k = tid; k < 4u * top_n; k += kBvhThreads) lds_top[k] = qnodes[k];
+    __syncthreads();
+    uint32_t *const sl = &lds_slot[wv][0][0];                             // word w of slot k: sl[w * kSlotN + k]
+    uint8_t *const done_list = &lds_lists[wv][0][0], *const ready_list = &lds_lists[wv][1][0];
+    const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
+    SlotRec *const recs = pool + ((size_t)blockIdx.x * WAVES + wv) * kSlotN;      // this wave's records
+    const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
+    const unsigned long long n_rays = *sq.count < sq.capacity ? *sq.count : sq.capacity;
+
+    unsigned long long wave_next = 0, wave_end = 0;
+    bool queue_empty = false;
+    uint32_t n_done = kSlotN, n_ready = 0;                                 // wave-uniform
+    for (uint32_t s = lane; s < (uint32_t)kSlotN; s += 64u) {             // every slot starts FREE: the first f64 phases fill them
+        done_list[s] = (uint8_t)s;
+        sl[9 * kSlotN + s] = kSlotFresh;
+    }
+    bool walking = false;
+    uint32_t slot = 0, node = kNone, sp = 0, qcnt = 0;
+    uint32_t nbox = 0, nleaf = 0, segs = 0;                               // per lane and launch: far below 2^32 (the host keeps a launch below 2^32 rays)
+    bool overflow = false;
+    float best_up = 0.f;
+    Ray32S q;
+    SphereRay sr;
+    q.ix = q.iy = q.iz = 1.f; q.nx = q.ny = q.nz = q.e = 0.f;
+    sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
+    unsigned long long exact = 0;                                         // (an exhaustive fallback adds n_spheres at a time)
+
+    for (;;) {
+        // ---- lanes whose walk has ended leave their slot DONE (its candidates are in its LDS words already)
+        {
+            const bool fin = walking && node == kNone;
+            const unsigned long long fmask = __ballot(fin);
+            if (fmask != 0ull) {
+                if (fin) {
+                    sl[8 * kSlotN + slot] = __float_as_uint(best_up);
+                    sl[9 * kSlotN + slot] = qcnt | (overflow ? kSlotOverflow : 0u);
+                    done_list[n_done + bvh_mbcnt(fmask)] = (uint8_t)slot;
+                    walking = false;
+                }
+                n_done += (uint32_t)__popcll(fmask);
+            }
+        }
+        // ---- idle lanes take READY slots (the list's tail): 16 LDS words into registers
+        unsigned long long idle_mask = __ballot(!walking);
+        uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (n_idle != 0u && n_ready != 0u) {
+            const uint32_t k = bvh_mbcnt(idle_mask);
+            if (!walking && k < n_ready) {
+                slot = ready_list[n_ready - 1u - k];
+                q.ix = __uint_as_float(sl[0 * kSlotN + slot]); q.iy = __uint_as_float(sl[1 * kSlotN + slot]); q.iz = __uint_as_float(sl[2 * kSlotN + slot]);
+                q.nx = __uint_as_float(sl[3 * kSlotN + slot]); q.ny = __uint_as_float(sl[4 * kSlotN + slot]); q.nz = __uint_as_float(sl[5 * kSlotN + slot]);
+                q.e = __uint_as_float(sl[6 * kSlotN + slot]);
+                sr.px = __uint_as_float(sl[7 * kSlotN + slot]); sr.py = __uint_as_float(sl[8 * kSlotN + slot]); sr.pz = __uint_as_float(sl[9 * kSlotN + slot]);
+                sr.dx = __uint_as_float(sl[10 * kSlotN + slot]); sr.dy = __uint_as_float(sl[11 * kSlotN + slot]); sr.dz = __uint_as_float(sl[12 * kSlotN + slot]);
+                sr.Kg = __uint_as_float(sl[13 * kSlotN + slot]); sr.c0 = __uint_as_float(sl[14 * kSlotN + slot]); sr.K = __uint_as_float(sl[15 * kSlotN + slot]);
+                node = sv.bvh_root; sp = 0; qcnt = 0; overflow = false; best_up = __builtin_inff();
+                walking = true;
+            }
+            n_ready -= n_idle < n_ready ? n_idle : n_ready;
+            idle_mask = __ballot(!walking);
+            n_idle = (uint32_t)__popcll(idle_mask);
+        }
+        // ---- the f64 phase, for up to 64 DONE slots (the head of the queue), when it runs full -- or the walk is starving
+        if (n_done >= 64u || (n_done != 0u && n_ready == 0u && (n_idle == 64u || n_idle >= kSlotServe))) {
+            const uint32_t take = n_done < 64u ? n_done : 64u;
+            const bool have = lane < take;
+            const uint32_t my = have ? (uint32_t)done_list[lane] : 0u;
+            {   // the rest of the queue moves up (at most kSlotN - 64 <= 64 entries: one per lane)
+                const uint32_t rest = n_done - take;
+                const uint32_t mv = lane < rest ? (uint32_t)done_list[take + lane] : 0u;
+                if (lane < rest) done_list[lane] = (uint8_t)mv;
+                n_done = rest;
+            }
+            SlotRec *const rec = recs + my;
+            uint32_t fl = have ? sl[9 * kSlotN + my] : 0u;
+            RayState r;
+            uint32_t ridx = 0;
+            bool go = false;                                            // this slot has a segment to set up
+            // (a) a slot whose walk ended: closest_object's exact part + ray_hit
+            if (have && (fl & kSlotFresh) == 0u) {
+                const double4 ra = rec->a, rb = rec->b, rc = rec->c, rd = rec->d;
+                r.pos = mk(ra.x, ra.y, ra.z);
+                r.dir = mk(ra.w, rb.x, rb.y);
+                r.result = mk(rb.z, rb.w, rc.x);
+                r.light = mk(rc.y, rc.z, rc.w);
+                r.key = (uint64_t)__double_as_longlong(rd.x);
+                const unsigned long long ib = (unsigned long long)__double_as_longlong(rd.y);
+                ridx = (uint32_t)ib;
+                r.bounce = (uint32_t)(ib >> 32);
+                r.draw = 6u + 2u * r.bounce;
+                const float bu = __uint_as_float(sl[8 * kSlotN + my]);
+                const RayX rx = make_rayx(r.pos, r.dir);
+                Hit h;
+                hit_init(h);
+                ++segs;
+                if ((fl & (kSlotOverflow | kSlotNoWalk)) == 0u) {
+                    const uint32_t nq = fl & 0xFFu;
+#pragma unroll 1
+                    for (uint32_t e = 0; e < nq; ++e) {
+                        if (__uint_as_float(sl[(size_t)(kSphQueue + e) * kSlotN + my]) <= bu) {
+                            const uint32_t idx = sl[(size_t)e * kSlotN + my];
+                            double t;
+                            if (sphere_distance(la.spheres[idx], rx, &t)) hit_consider(h, t, la.sphere_ids[idx], 0, idx);
+                            exact += 1;
+                        }
+                    }
+                } else {                                  // no walk (origin out of range / NaN) or a dropped candidate: every sphere
+                    for (uint32_t k = 0; k < sv.n_spheres; ++k) {
+                        double t;
+                        if (sphere_distance(la.spheres[k], rx, &t)) hit_consider(h, t, la.sphere_ids[k], 0, k);
+                    }
+                    exact += sv.n_spheres;
+                }
+                for (uint32_t k = 0; k < sv.n_planes; ++k) {
+                    double t;
+                    if (plane_distance(sv.planes[k], rx, &t)) hit_consider(h, t, sv.planes[k].id, 1, k);
+                }
+                for (uint32_t k = 0; k < sv.n_tri_filter; ++k) {       // the few triangles of a sphere scene (none of them in the tree)
+                    const uint32_t tk = la.tri_fidx[k];
+                    double t;
+                    if (triangle_distance(la.tris[tk], rx, &t)) hit_consider(h, t, la.tris[tk].id, 2, tk);
+                }
+                exact += sv.n_planes + sv.n_tri_filter;
+                bool done = true;
+                if (h.id != kNone) {
+                    advance_and_shade(sv, h, r);
+                    done = (r.bounce >= bounce_limit) || light_is_zero(r);            // scene.rs:227-228
+                }
+                if (done) {
+                    store_sample(samples, rv, ridx, r.result);
+                    fl = kSlotFresh;                                    // the slot is free for the next survivor
+                } else go = true;
+            }
+            // (b) a free slot: the next survivor of stage 1's queue, as it is after its first hit
+            const unsigned long long fm = __ballot(have && (fl & kSlotFresh) != 0u);
+            bool dead = false;
+            if (fm != 0ull) {
+                if (wave_next >= wave_end && !queue_empty) {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(work_counter, (unsigned long long)rv.grab);
+                    b = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        __builtin_amdgcn_readfirstlane((uint32_t)b);
+                    wave_next = b;
+                    wave_end = b + rv.grab < n_rays ? b + rv.grab : n_rays;
+                    if (b >= n_rays) { queue_empty = true; wave_next = wave_end = 0; }
+                }
+                if (have && (fl & kSlotFresh) != 0u) {
+                    const unsigned long long qi = wave_next + bvh_mbcnt(fm);
+                    if (qi < wave_end) {
+                        const double4 *p = reinterpret_cast<const double4 *>(sq.rec + (sq.perm ? (unsigned long long)sq.perm[qi] : qi));
+                        const double4 s0 = p[0], s1 = p[1];
+                        ridx = (uint32_t)(unsigned long long)__double_as_longlong(s1.z);
+                        if (ridx != kNone) {
+                            uint32_t pl = 0, smp = 0;
+                            if (rv.tiles_x != 0u) (void)ray_index_to_pixel_tiled(rv, ridx, pl, smp);
+                            else ray_index_to_pixel(rv, ridx, pl, smp);
+                            const uint32_t k = fastdiv(pl, rv.div_width), x = pl - k * rv.width;
+                            const uint64_t pix = (uint64_t)image_row(rv, k) * rv.width + x;
+                            r.key = rng_key(sv.seed, pix, rv.sample_begin + smp);
+                            r.bounce = 1u;
+                            r.draw = 8u;
+                            r.pos = mk(s0.x, s0.y, s0.z);
+                            r.dir = mk(s0.w, s1.x, s1.y);
+                            // ray_hit's two folds of the first hit (scene.rs:276-277) from resulting_color = 0, light_color = 1 (ray.rs:18-19)
+                            const MaterialX m = sv.materials[(uint32_t)((unsigned long long)__double_as_longlong(s1.z) >> 32)];
+                            r.result = vadd(mk(0.0, 0.0, 0.0), vmulv(mk(1.0, 1.0, 1.0), m.emission_color));
+                            r.light = vmulv(mk(1.0, 1.0, 1.0), m.base_color);
+                            go = true;
+                        }                                                // (a slot its wave reserved and did not use: asked again next time)
+                    } else if (queue_empty) dead = true;                 // nothing left to take: the slot retires
+                }
+                const unsigned long long taken = (unsigned long long)__popcll(fm);
+                wave_next = wave_next + taken < wave_end ? wave_next + taken : wave_end;
+            }
+            // (c) the segment's set-up: the walk's f32 parameters into the slot's LDS words, the path state back to its record
+            bool nowalk = false;
+            if (go) {
+                const RayX rn = make_rayx(r.pos, r.dir);
+                const float omax = fmaxf(fmaxf(__builtin_fabsf((float)r.pos.x), __builtin_fabsf((float)r.pos.y)),
+                                         __builtin_fabsf((float)r.pos.z));
+                const bool in32 = omax <= sv.bvh_origin_limit;                              // NaN origin -> no walk
+                if (in32 || omax <= sv.bvh_origin_limit * kBvhRange64) {
+                    SphereRay s2;
+                    sphere_ray_from(sv, r.pos, r.dir, s2);
+                    Ray32 q0;
+                    make_ray32(r.pos, rn.dirn, (double)sv.bvh_inv_max, q0);
+                    sl[0 * kSlotN + my] = __float_as_uint(q0.ix); sl[1 * kSlotN + my] = __float_as_uint(q0.iy); sl[2 * kSlotN + my] = __float_as_uint(q0.iz);
+                    sl[3 * kSlotN + my] = __float_as_uint(q0.nx); sl[4 * kSlotN + my] = __float_as_uint(q0.ny); sl[5 * kSlotN + my] = __float_as_uint(q0.nz);
+                    sl[6 * kSlotN + my] = __float_as_uint(ray32_slack(q0.nx, q0.ny, q0.nz, in32));
+                    sl[7 * kSlotN + my] = __float_as_uint(s2.px); sl[8 * kSlotN + my] = __float_as_uint(s2.py); sl[9 * kSlotN + my] = __float_as_uint(s2.pz);
+                    sl[10 * kSlotN + my] = __float_as_uint(s2.dx); sl[11 * kSlotN + my] = __float_as_uint(s2.dy); sl[12 * kSlotN + my] = __float_as_uint(s2.dz);
+                    sl[13 * kSlotN + my] = __float_as_uint(s2.Kg); sl[14 * kSlotN + my] = __float_as_uint(s2.c0); sl[15 * kSlotN + my] = __float_as_uint(s2.K);
+                } else nowalk = true;
+                rec->a = make_double4(r.pos.x, r.pos.y, r.pos.z, r.dir.x);
+                rec->b = make_double4(r.dir.y, r.dir.z, r.result.x, r.result.y);
+                rec->c = make_double4(r.result.z, r.light.x, r.light.y, r.light.z);
+                rec->d = make_double4(__longlong_as_double((long long)r.key),
+                                      __longlong_as_double((long long)(((unsigned long long)r.bounce << 32) | (unsigned long long)ridx)), 0.0, 0.0);
+                if (nowalk) { sl[9 * kSlotN + my] = kSlotNoWalk; sl[8 * kSlotN + my] = __float_as_uint(__builtin_inff()); }
+            } else if (have && !dead) {
+                sl[9 * kSlotN + my] = kSlotFresh;                       // a free slot that got no survivor this time
+            }
+            // READY: set up and walkable.  DONE again: no walk possible (tested exhaustively next phase), or still free.
+            const bool to_ready = go && !nowalk, to_done = have && !dead && !to_ready;
+            const unsigned long long rm = __ballot(to_ready), dm = __ballot(to_done);
+            if (to_ready) ready_list[n_ready + bvh_mbcnt(rm)] = (uint8_t)my;
+            if (to_done) done_list[n_done + bvh_mbcnt(dm)] = (uint8_t)my;
+            n_ready += (uint32_t)__popcll(rm);
+            n_done += (uint32_t)__popcll(dm);
+#ifndef RTX_SLOT_NOFENCE
+            __threadfence_block();                                      // the records are read by other lanes of this wave, later
+#endif
+            // free slots while the queue still has chunks are asked again; when it is empty they retired above, so a phase that
+            // only re-queued free slots cannot repeat for ever
+            continue;
+        }
+        if (n_idle == 64u) break;                  // nothing walking, nothing READY, nothing DONE: every slot retired
+        // ---- the walk: node visits and leaf visits apart (sphere_walk_phased's iteration) for every lane that has an entry to
+        //      open, until kSlotWait lanes have finished their walk (they are then served together), or nobody walks any more.
+        //      A tight loop of its own: what the f64 phase spills stays outside it.
+        for (;;) {
+            const bool w = walking && node != kNone;
+            const bool at_leaf = w && (node >> 29) != 0u;
+            const unsigned long long lm = __ballot(at_leaf), am = __ballot(w);
+            if (am == 0ull) break;
+            if ((uint32_t)__popcll(lm) >= kSphLeafLanes || lm == am) {
+                if (at_leaf)
+                    sphere_leaf_step_at<STACK, SPILL, kSlotN>(la.sphere_f32, la.sphere_prims, sr, node, sp, &lds_stack[0][0], sl, tid, slot, spill,
+                                                              spill_stride, glane, best_up, qcnt, overflow, nleaf);
+            } else if (w && !at_leaf) {
+#if defined(RTX_LAB) && defined(RTX_SLOT_COUNT_TOP)          // lab build: node visits served from the LDS copy, reported through exact_tests
+                if (node < (uint32_t)(RTX_SLOT_COUNT_TOP)) exact += 1;
+#endif
+                sphere_node_step_q3<STACK, SPILL>(qnodes, q, node, sp, &lds_stack[0][0], tid, spill, spill_entries, spill_stride, glane, best_up,
+                                                  overflow, nbox, kSlotTop > 0 ? (LdsF4Ptr)&lds_top[0] : (LdsF4Ptr) nullptr, top_n);
+            }
+            const uint32_t n_fin = (uint32_t)__popcll(__ballot(walking && node == kNone));
+            if (n_fin >= kSlotWait) break;
+        }
+    }
+    unsigned long long box_tests = nbox, filt = (unsigned long long)nbox + nleaf, segs64 = segs;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        segs64 += __shfl_xor(segs64, off, 64);
+        exact += __shfl_xor(exact, off, 64);
+        filt += __shfl_xor(filt, off, 64);
+        box_tests += __shfl_xor(box_tests, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t shard = (blockIdx.x * (kBvhThreads >> 6) + (tid >> 6)) & (kCounterShards - 1);
+        if (segs64) atomicAdd(&ctr[shard].segments, segs64);
+        if (exact) atomicAdd(&ctr[shard].exact_tests, exact);
+        if (filt) atomicAdd(&ctr[shard].filter_tests, filt);
+        if (box_tests) atomicAdd(&ctr[2 + (shard % (kCounterShards - 2))].pad_, box_tests);
     }
 }
 

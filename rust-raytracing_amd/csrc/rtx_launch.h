@@ -46,8 +46,11 @@ bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot = nullptr,
-                                    hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr);
+                                    hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr, void *slots_mem = nullptr);
 #ifdef RTX_LAB
+// slots_mem: bvh_spheres_slots_bytes(n_cus) bytes of device memory, or null: with it stage 2 of the two-stage form runs over ray
+// slots (trace_sph_slots_kernel: the f64 path state of the rays in flight, one 128-byte record per slot)
+size_t bvh_spheres_slots_bytes(int n_cus);
 // pool_mem: bvh_spheres_pool2_bytes(n_cus) bytes: stage 2 runs as a wave-local pool of ray slots (flags bit 2: the lock-step form)
 size_t bvh_spheres_pool2_bytes(int n_cus);
 size_t bvh_spheres_pair_bytes(int n_cus);      // flags bit 3: stage 2 with two rays per lane; pool_mem then holds this many bytes

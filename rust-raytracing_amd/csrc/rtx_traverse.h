@@ -133,6 +133,7 @@ __device__ __forceinline__ float round_up32(double best)
 // wave-uniform reads through the scalar cache: the constant address space makes the compiler select s_load for them
 // (the packet walks of rtx_wavefront.hip and rtx_bvh_spheres.hip: one request per wave instead of 64 address-divergent ones)
 typedef float PkF4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) PkF4 *LdsF4Ptr;      // a pointer into LDS, typed as such (ds_read, never flat)
 struct PkConst4 {
     const __attribute__((address_space(4))) PkF4 *p;
     __device__ __forceinline__ PkConst4 operator+(size_t i) const { return PkConst4{p + i}; }
@@ -658,14 +659,26 @@ __device__ __forceinline__ void bvh_traverse_spheres(const float4 *__restrict__ 
 // wave: leaves when at least `leaf_lanes` lanes hold one, or nobody holds a node.  Both kinds of code run with the lanes that
 // need them, the node visit has no leaf code in it, and the leaves come in distance order with the nodes.
 // Every leaf a ray enters is still bounded with the lane's own best_up before the walk ends: same candidates for the exact tests.
+// lds_top / top_n (optional): an LDS copy of nodes [0, top_n) -- the top of the tree, which every walk passes through
+// (collapse_to_bvh4 numbers it first).  A per-lane walk fetches its node as four address-divergent 16-byte requests and the CU's L1
+// serves about one such request per cycle: with the lanes kept busy (the slot kernel) that rate, not the VALUs, bounds the walk
+// (LAB_NOTEBOOK R4.3), and the top levels are half of a walk's visits.
 template <int STACK, bool SPILL, class RAY>
 __device__ __forceinline__ void sphere_node_step_q3(const float4 *__restrict__ qnodes, const RAY &q, uint32_t &node, uint32_t &sp,
                                                     uint32_t *lds_stack, uint32_t tid, uint32_t *__restrict__ spill,
                                                     uint32_t spill_entries, size_t spill_stride, size_t glane, float best_up,
-                                                    bool &overflow, uint32_t &nbox)
+                                                    bool &overflow, uint32_t &nbox, LdsF4Ptr lds_top = nullptr, uint32_t top_n = 0u)
 {
-    const float4 *np = qnodes + 4 * (size_t)node;
-    const float4 h0 = np[0], h1 = np[1], h2 = np[2], h3 = np[3];
+    float4 h0, h1, h2, h3;
+    if (lds_top != nullptr && node < top_n) {             // (an LDS-typed pointer: ds_read_b128, not a flat load of a selected address)
+        LdsF4Ptr lp = lds_top + 4 * node;
+        const PkF4 v0 = lp[0], v1 = lp[1], v2 = lp[2], v3 = lp[3];
+        h0 = make_float4(v0.x, v0.y, v0.z, v0.w); h1 = make_float4(v1.x, v1.y, v1.z, v1.w);
+        h2 = make_float4(v2.x, v2.y, v2.z, v2.w); h3 = make_float4(v3.x, v3.y, v3.z, v3.w);
+    } else {
+        const float4 *np = qnodes + 4 * (size_t)node;
+        h0 = np[0]; h1 = np[1]; h2 = np[2]; h3 = np[3];
+    }
     const float Sx = h0.w * q.ix, Sy = h1.x * q.iy, Sz = h1.y * q.iz;
     const float Ox = __builtin_fmaf(h0.x, q.ix, q.nx), Oy = __builtin_fmaf(h0.y, q.iy, q.ny), Oz = __builtin_fmaf(h0.z, q.iz, q.nz);
     const uint32_t lox = __float_as_uint(h1.z), loy = __float_as_uint(h1.w), loz = __float_as_uint(h2.x);
@@ -731,11 +744,13 @@ __device__ __forceinline__ void sphere_node_step_q3(const float4 *__restrict__ q
 }
 
 // The leaf `ref` (type << 29 | first record, type = its 1..6 spheres): sphere_step's bounds for each record, then the next entry.
-template <int STACK, bool SPILL>
-__device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf_f32, const uint32_t *__restrict__ leaf_prims,
-                                                 const SphereRay &sr, uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
-                                                 uint32_t tid, uint32_t *__restrict__ spill, size_t spill_stride, size_t glane,
-                                                 float &best_up, uint32_t &qcnt, bool &overflow, uint32_t &nleaf)
+// The candidate queue is column `qcol` of an LDS array of 2 * kSphQueue rows, QS words per row (the lock-step kernels: the lane's
+// own column of lds_q[.][kBvhThreads]; the slot kernel: the column of the ray slot the lane walks).
+template <int STACK, bool SPILL, int QS>
+__device__ __forceinline__ void sphere_leaf_step_at(const float4 *__restrict__ leaf_f32, const uint32_t *__restrict__ leaf_prims,
+                                                    const SphereRay &sr, uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                                    uint32_t tid, uint32_t qcol, uint32_t *__restrict__ spill, size_t spill_stride, size_t glane,
+                                                    float &best_up, uint32_t &qcnt, bool &overflow, uint32_t &nleaf)
 {
     const uint32_t first = node & 0x1FFFFFFFu, n = node >> 29;
     for (uint32_t k = 0; k < n; ++k) {
@@ -757,11 +772,11 @@ __device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf
                     uint32_t w = 0;
 #pragma unroll
                     for (int e2 = 0; e2 < kSphQueue; ++e2) {
-                        const uint32_t ie = lds_q[(size_t)e2 * kBvhThreads + tid];
-                        const uint32_t te = lds_q[(size_t)(kSphQueue + e2) * kBvhThreads + tid];
+                        const uint32_t ie = lds_q[(size_t)e2 * QS + qcol];
+                        const uint32_t te = lds_q[(size_t)(kSphQueue + e2) * QS + qcol];
                         if (__uint_as_float(te) <= best_up) {
-                            lds_q[(size_t)w * kBvhThreads + tid] = ie;
-                            lds_q[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                            lds_q[(size_t)w * QS + qcol] = ie;
+                            lds_q[(size_t)(kSphQueue + w) * QS + qcol] = te;
                             w += 1;
                         }
                     }
@@ -769,8 +784,8 @@ __device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf
                 }
                 if (qcnt == (uint32_t)kSphQueue) overflow = true;
                 else {
-                    lds_q[(size_t)qcnt * kBvhThreads + tid] = leaf_prims[first + k];
-                    lds_q[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                    lds_q[(size_t)qcnt * QS + qcol] = leaf_prims[first + k];
+                    lds_q[(size_t)(kSphQueue + qcnt) * QS + qcol] = __float_as_uint(tlo);
                     qcnt += 1;
                 }
             }
@@ -783,6 +798,16 @@ __device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf
         node = (!SPILL || sp < (uint32_t)STACK) ? lds_stack[(size_t)sp * kBvhThreads + tid]
                                                 : spill[(size_t)(sp - (uint32_t)STACK) * spill_stride + glane];
     }
+}
+
+template <int STACK, bool SPILL>
+__device__ __forceinline__ void sphere_leaf_step(const float4 *__restrict__ leaf_f32, const uint32_t *__restrict__ leaf_prims,
+                                                 const SphereRay &sr, uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t *lds_q,
+                                                 uint32_t tid, uint32_t *__restrict__ spill, size_t spill_stride, size_t glane,
+                                                 float &best_up, uint32_t &qcnt, bool &overflow, uint32_t &nleaf)
+{
+    sphere_leaf_step_at<STACK, SPILL, kBvhThreads>(leaf_f32, leaf_prims, sr, node, sp, lds_stack, lds_q, tid, tid, spill, spill_stride, glane,
+                                                   best_up, qcnt, overflow, nleaf);
 }
 
 #if defined(RTX_LAB) && defined(RTX_SPH_PROFILE)          // lab build (-DRTX_SPH_PROFILE=k): one per-lane count per build, summed and reported through exact_tests
@@ -816,6 +841,9 @@ __device__ __forceinline__ void sphere_walk_phased(const float4 *__restrict__ qn
             if (RTX_SPH_PROFILE == 7) rtx_prof += 1;
         }
 #endif
+#if defined(RTX_LAB) && defined(RTX_SPH_PROFILE) && RTX_SPH_PROFILE == 9
+        const uint32_t sp_before = sp;              // lab build: pushes that take the stack above RTX_SPH_PROFILE_SP entries (what a shorter LDS stack would spill)
+#endif
         if ((uint32_t)__popcll(lm) >= leaf_lanes || lm == am) {
             if (at_leaf)
                 sphere_leaf_step<STACK, SPILL>(leaf_f32, leaf_prims, sr, node, sp, lds_stack, lds_q, tid, spill, spill_stride, glane,
@@ -824,6 +852,9 @@ __device__ __forceinline__ void sphere_walk_phased(const float4 *__restrict__ qn
             sphere_node_step_q3<STACK, SPILL>(qnodes, q, node, sp, lds_stack, tid, spill, spill_entries, spill_stride, glane, best_up,
                                               overflow, nbox);
         }
+#if defined(RTX_LAB) && defined(RTX_SPH_PROFILE) && RTX_SPH_PROFILE == 9
+        if (sp_before <= (uint32_t)(RTX_SPH_PROFILE_SP) && sp > (uint32_t)(RTX_SPH_PROFILE_SP)) rtx_prof += 1;
+#endif
         const uint32_t still = (uint32_t)__popcll(__ballot(node != kNone));
         if (still < cut_walkers && n_alive - still >= cut_done) break;
     }

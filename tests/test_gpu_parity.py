@@ -202,7 +202,8 @@ def test_closed_box_at_two_stage_size_every_ray_survives(gpu):
     import closed_form as cf
     box = cf.closed_box(gpu.OBJECT_DTYPE, 300, seed=8)
     w = h = 1024
-    for tune in (0, gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_NO_CUT, gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_STAGE2_PAIR, gpu.RTX_TUNE_STAGE2_POOL):
+    for tune in (0, gpu.RTX_TUNE_STAGE2_SLOTS, gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_NO_CUT, gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_STAGE2_PAIR,
+                 gpu.RTX_TUNE_STAGE2_POOL):
         hnd = hip_scene(gpu, box, cam=((0.3, -0.2, 0.1), (1.0, 0.1, -0.05), 1.5), rays_per_pixel=1, seed=3, tuning=tune).upload(0)
         buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
         st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
@@ -395,6 +396,7 @@ def test_spheres_kernel_paths(gpu, oracle):
         L, BVH = gpu.LabKernel, gpu.RTX_KERNEL_BVH
         for kern, tune, ran in ((BVH, 0, BVH), (BVH, gpu.RTX_TUNE_TWO_STAGE, BVH),
                                 (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_CUT, BVH),
+                                (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_SLOTS, BVH),
                                 (gpu.RTX_KERNEL_BVH_REGROUP, 0, BVH), (gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_TWO_STAGE, BVH),
                                 (L(BVH), 0, BVH), (L(BVH), gpu.RTX_TUNE_TWO_STAGE, BVH),
                                 (BVH, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_PACKETS, BVH),
@@ -648,7 +650,8 @@ def test_ab_knobs_keep_the_bits(gpu):
              gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_TWO_STAGE, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_SORT_SURVIVORS,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR | gpu.RTX_TUNE_NO_QNODES, gpu.RTX_TUNE_PK_LDS_STACK, gpu.RTX_TUNE_BEAMS, gpu.RTX_TUNE_BEAMS | gpu.RTX_TUNE_PK_LDS_STACK, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_CUT, gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_NO_CUT,
-             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_INLINE_LEAVES | gpu.RTX_TUNE_NO_CUT]
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_INLINE_LEAVES | gpu.RTX_TUNE_NO_CUT,
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_SLOTS, gpu.RTX_TUNE_STAGE2_SLOTS]
     # a knob with a RTX_TUNE_LAB_MASK bit renders through librtx_hip_lab.so (the product library refuses it, below); the others
     # through the product library and, as LabKernel ids, through the lab library's kernel family of each id
     L = gpu.LabKernel
