@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
     const uint32_t lane = tid & 63u;
     const size_t spill_stride = (size_t)gridDim.x * kBvhThreads, glane = (size_t)blockIdx.x * kBvhThreads + tid;
     const uint32_t bounce_limit = sv.max_bounces >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)sv.max_bounces + 1u;
-    enum : uint32_t { S_IDLE = 0, S_TRAV = 1, S_FIN = 2, S_SETUP = 3, S_FLUSH = 4 };
+    enum : uint32_t { S_IDLE = 0, S_TRAV = 1, S_FIN = 2, S_SETUP = 3, S_FLUSH = 4, S_POINT = 5 };
 
     unsigned long long wave_next = 0, wave_end = 0;      // this wave's share of the ray queue (wave-uniform)
     bool queue_empty = false;
@@ -91,15 +91,26 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
     bool overflow = false, tree_used = false;
     uint32_t ridx = 0;
     uint32_t left_tri = kNone;               // the triangle (index in tris[]) the ray has just bounced off, if any
+    // the triangles near the point the ray sits on (rtx_mesh_step.h, mesh_point_query): the key -- the point as the filter sees
+    // it and the triangle it is on --, their number (kPointCacheBad: too many, walk) and their filter records
+    uint32_t ck_x = 0x7FC00000u, ck_y = 0u, ck_z = 0u, ck_tri = kNone, c_n = 0u, c0 = 0u, c1 = 0u, c2 = 0u;
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
     hit_init(h);
     tri_filter_idle(tpar);
     q.ix = q.iy = q.iz = q.nx = q.ny = q.nz = 0.f;
     sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
 
+#if defined(RTX_LAB) && defined(RTX_MESH_PROFILE)      // lab build: one count per build, reported through exact_tests
+    unsigned long long rtx_prof = 0;
+#define RTX_MPROF(k, cond, inc) { if (RTX_MESH_PROFILE == (k) && (cond)) rtx_prof += (inc); }
+#else
+#define RTX_MPROF(k, cond, inc)
+#endif
     for (;;) {
         // ================= the f64 phase (entered when the inner loop below finds it due) =================
         if (__ballot(state != S_IDLE) == 0ull && queue_empty) break;       // wave-uniform: nothing live, nothing left to take
+        RTX_MPROF(1, lane == 0, 1)                                          // outer iterations (f64 phases) per wave
+        RTX_MPROF(2, state == S_FIN || state == S_FLUSH, 1)                 // lanes served by them
         if (state == S_FIN || state == S_FLUSH) {
             // ---- exact tests (sphere.rs:19-30, triangle.rs:108-127) of the candidates that can still be the winner
             const RayX rx = make_rayx(r.pos, r.dir);
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
             wave_next = wave_next + taken < wave_end ? wave_next + taken : wave_end;
         }
         // ---- set up the next segment
+        RTX_MPROF(3, state == S_SETUP, 1)                                   // lanes set up
         if (state == S_SETUP) {
             const RayX rx = make_rayx(r.pos, r.dir);
             hit_init(h);
@@ -233,10 +245,42 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
             if (tree_used) {
                 if constexpr (!PLAIN) { if (sv.bvh_flags & 1u) sphere_ray_from(sv, r.pos, r.dir, sr); }
                 tri_filter_from_ray(sv, r.pos, r.dir, tpar);
-                make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
-                node = sv.bvh_root;              // wide node 0 (flagged when it is a footprint node)
-                if constexpr (kSplit) { if (PLAIN == 2) node &= ~kBvhFlatNode; pend.n = 0u; }
-                state = S_TRAV;
+                bool walk = true;
+                if constexpr (PLAIN == 2 && kSplit) {
+                    // a self-hit close enough for the point's set to decide it (t_self <= tau = tpar.A / 4): exact tests only, no walk
+                    // -- after ONE point location per point, which runs in the traversal loop below (S_POINT)
+                    if (h.id != kNone && left_tri != kNone && tpar.A < 1.0e29f && h.t <= (double)(tpar.A * 0.25f)) {
+                        const bool same = __float_as_uint(tpar.npx) == ck_x && __float_as_uint(tpar.npy) == ck_y &&
+                                          __float_as_uint(tpar.npz) == ck_z && left_tri == ck_tri;
+                        if (!same) {
+                            ck_x = __float_as_uint(tpar.npx); ck_y = __float_as_uint(tpar.npy); ck_z = __float_as_uint(tpar.npz);
+                            ck_tri = left_tri;
+                            c_n = 0u;
+                            make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);      // (should the set turn out unusable: the walk's ray)
+                            node = sv.bvh_root & ~kBvhFlatNode;
+                            if constexpr (kSplit) pend.n = 0u;
+                            state = S_POINT;
+                            walk = false;
+                        } else if (c_n <= kPointCache) {
+                            if (c_n > 0u) { lq[(size_t)0 * kBvhThreads + tid] = c0 | kQueueTri; lq[(size_t)(kMeshQueue + 0) * kBvhThreads + tid] = 0u; }
+                            if (c_n > 1u) { lq[(size_t)1 * kBvhThreads + tid] = c1 | kQueueTri; lq[(size_t)(kMeshQueue + 1) * kBvhThreads + tid] = 0u; }
+                            if (c_n > 2u) { lq[(size_t)2 * kBvhThreads + tid] = c2 | kQueueTri; lq[(size_t)(kMeshQueue + 2) * kBvhThreads + tid] = 0u; }
+                            qcnt = c_n;
+                            node = kNone;
+                            if constexpr (kSplit) pend.n = 0u;
+                            state = S_FIN;
+                            walk = false;
+                        }
+                    }
+                }
+                RTX_MPROF(7, walk, 1)                                       // segments that walk
+                RTX_MPROF(8, state == S_POINT, 1)                           // segments that locate their point
+                if (walk) {
+                    make_ray32(r.pos, rx.dirn, (double)sv.bvh_inv_max, q);
+                    node = sv.bvh_root;              // wide node 0 (flagged when it is a footprint node)
+                    if constexpr (kSplit) { if (PLAIN == 2) node &= ~kBvhFlatNode; pend.n = 0u; }
+                    state = S_TRAV;
+                }
             } else {
                 if (omax <= sv.bvh_origin_limit * kBvhRange64) {
                     // origin far outside the scene (rare: a bounce off one of the reference's far phantom hits): the whole
@@ -282,6 +326,37 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
             if constexpr (kMeshPipe) { if (state == S_TRAV) mesh_load_node<PLAIN>(nodes, resume != 0u ? resume_node : node, nd); }
             if constexpr (kSplit) {
                 for (;;) {
+                    RTX_MPROF(4, lane == 0, 1)                              // traversal-loop iterations per wave
+                    RTX_MPROF(5, state == S_TRAV, 1)                        // lanes walking in them
+                    RTX_MPROF(6, state == S_POINT, 1)                       // lanes locating their point in them
+                    if constexpr (PLAIN == 2) {
+                        // the lanes that locate their point: one node each; a finished set sends its lane to its exact tests (or,
+                        // unusable, into the ordinary walk of this segment)
+                        const bool pt = state == S_POINT;
+                        if (__ballot(pt) != 0ull) {
+                            if (pt) {
+                                mesh_point_step<STACKN>(nodes, ma, la.tri_fidx, (float)r.pos.x, (float)r.pos.y, tpar,
+                                                        tpar.A + sv.bvh_origin_limit * 9.5367432e-7f, left_tri, node, sp, ls, tid, c_n, c0, c1, c2,
+                                                        nbox, nleaf);
+                                if (node == kNone || c_n == kPointCacheBad) {
+                                    sp = 0;
+                                    if (c_n <= kPointCache) {
+                                        if (c_n > 0u) { lq[(size_t)0 * kBvhThreads + tid] = c0 | kQueueTri; lq[(size_t)(kMeshQueue + 0) * kBvhThreads + tid] = 0u; }
+                                        if (c_n > 1u) { lq[(size_t)1 * kBvhThreads + tid] = c1 | kQueueTri; lq[(size_t)(kMeshQueue + 1) * kBvhThreads + tid] = 0u; }
+                                        if (c_n > 2u) { lq[(size_t)2 * kBvhThreads + tid] = c2 | kQueueTri; lq[(size_t)(kMeshQueue + 2) * kBvhThreads + tid] = 0u; }
+                                        qcnt = c_n;
+                                        node = kNone;
+                                        state = S_FIN;
+                                    } else {
+                                        qcnt = 0;
+                                        node = sv.bvh_root & ~kBvhFlatNode;
+                                        pend.n = 0u;
+                                        state = S_TRAV;
+                                    }
+                                }
+                            }
+                        }
+                    }
                     const bool trav = state == S_TRAV;
                     const bool has_leaf = trav && pend.n != 0u, can_open = trav && pend.n == 0u && node != kNone;
                     const uint32_t n_leaf = (uint32_t)__popcll(__ballot(has_leaf)), n_open = (uint32_t)__popcll(__ballot(can_open));
@@ -301,7 +376,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                         }
                     }
                     if (state == S_TRAV && pend.n == 0u && node == kNone) state = S_FIN;
-                    const unsigned long long m_trav = __ballot(state == S_TRAV);
+                    const unsigned long long m_trav = __ballot(state == S_TRAV || state == S_POINT);
                     const uint32_t waiting = (uint32_t)__popcll(__ballot(state == S_FIN || state == S_FLUSH)) +
                                              (queue_empty ? 0u : (uint32_t)__popcll(__ballot(state == S_IDLE)));
                     if (waiting >= thresh || m_trav == 0ull) break;
@@ -321,6 +396,9 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
             }
         }
     }
+#if defined(RTX_LAB) && defined(RTX_MESH_PROFILE)
+    exact = rtx_prof;
+#endif
     unsigned long long filt = box_tests + leaf_filters;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -412,6 +412,71 @@ __device__ __forceinline__ bool qleaf_read(const MeshArrays &ma, const TriFilter
     return true;
 }
 
+// ---- a segment that starts ON the triangle it has just left: no walk ----------------------------------------------------------
+// A ray that bounces off a triangle of a mesh re-hits that triangle at |t| ~ 1e-16 (no epsilon anywhere in the
+// reference), bounces again from the same point, re-hits again ... until the bounce limit: 6 of C5's 7.2 segments per ray and
+// 2.8 of C3's 3.8 are such self-hits, and every one of them used to walk the tree -- a point location in a tree of 2-D
+// footprints that overlap ~12-fold: ~85 node visits, ~60 filter records, 10 KB of memory traffic (C5: 137 GB per launch).
+// The self-hit itself is found exactly in the set-up phase (the triangle the ray left is tested first).  What the walk adds is the
+// proof that no OTHER triangle is at most as far: t_k <= t_self.  That proof does not depend on the direction:
+//     a triangle k the reference reports at distance t_k has the point q = p + d t_k in its plane and its footprint (Triangle::
+//     contains, triangle.rs:37-101: q's projection inside the projected triangle, hence inside its bounding rectangle); |d| = 1,
+//     so with t_k <= tau:  dist(p, plane_k) <= tau  and  p.xy within tau of rectangle_k.
+// So for an origin p the set  C(p) = { k : |n_k . (v0_k - p)| <= T, p.xy within T of rectangle_k },  T >= tau + roundings, holds
+// every triangle that can beat or tie a self-hit with t_self <= tau from p -- whatever the direction.  It is computed ONCE per
+// point (mesh_point_step: containment tests only, no slabs, no ordering, no bounds; the lanes that locate a point do so in the
+// kernel's traversal loop, a node per iteration, beside the lanes that walk) and kept in three registers (it is {} for a random
+// mesh: the triangle itself is excluded); the following segments from that point go straight to their exact tests.
+// Roundings, with S >= every coordinate magnitude (tri_filter_from_ray), u = 2^-24: the f32 key identifies p to 2^-23 S, nv is
+// evaluated to 16uS = 2^-20 S, rectangles decode to 2^-24 of their coordinates; tau = 2^-20 S = tpar.A / 4 and T = tpar.A = 2^-18 S
+// cover them with room to spare (T >= tau + 2 * 2^-23 S * sqrt(3) + 2^-20 S).
+constexpr uint32_t kPointCache = 3, kPointCacheBad = 0xFFu;
+
+// One node of the point location: the children whose rectangle holds the point (within Tb) are pushed / entered, the records of
+// such a leaf are tested on the spot.  node == kNone afterwards: the set is complete (c_n: its size, kPointCacheBad: no usable set).
+template <int STACK>
+__device__ __forceinline__ void mesh_point_step(const float4 *__restrict__ qnodes, const MeshArrays &ma, const uint32_t *__restrict__ tri_fidx,
+                                                float px, float py, const TriFilterParams &tpar, float Tb, uint32_t self_tri,
+                                                uint32_t &node, uint32_t &sp, uint32_t *lds_stack, uint32_t tid,
+                                                uint32_t &c_n, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &nbox, uint32_t &nleaf)
+{
+    const float T = tpar.A;
+    const float rx = -tpar.npx, ry = -tpar.npy;                         // the point relative to the scene centre (the records' frame)
+    const float4 *np = qnodes + 4 * (size_t)node;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const uint32_t w[4] = { __float_as_uint(n3.x), __float_as_uint(n3.y), __float_as_uint(n3.z), __float_as_uint(n3.w) };
+    const uint32_t qx[4] = { __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w) };
+    const uint32_t qy[4] = { __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w) };
+    uint32_t next = kNone;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t type = w[c] >> kQNodeShift, idx = w[c] & kQNodeIndexMask;
+        const float lox = __builtin_fmaf((float)(qx[c] & 0xFFFFu), n0.z, n0.x), hix = __builtin_fmaf((float)(qx[c] >> 16), n0.z, n0.x);
+        const float loy = __builtin_fmaf((float)(qy[c] & 0xFFFFu), n0.w, n0.y), hiy = __builtin_fmaf((float)(qy[c] >> 16), n0.w, n0.y);
+        const bool in = type != kQNodeEmpty && px >= lox - Tb && px <= hix + Tb && py >= loy - Tb && py <= hiy + Tb;
+        if (!in) continue;
+        if (type == 0u) {                                              // an interior child whose rectangle holds the point
+            if (next == kNone) next = idx;
+            else if (sp < (uint32_t)STACK) { lds_stack[(size_t)sp * kBvhThreads + tid] = idx; sp += 1; }
+            else c_n = kPointCacheBad;                                 // (deeper than the LDS stack: no set for this point, its segments walk)
+        } else {
+            for (uint32_t k = 0; k < type; ++k) {
+                const float4 A = ma.tri_f32[2 * (size_t)(idx + k)], B = ma.tri_f32[2 * (size_t)(idx + k) + 1];
+                const float nv = __builtin_fmaf(A.x, tpar.npx, __builtin_fmaf(A.y, tpar.npy, __builtin_fmaf(A.z, tpar.npz, A.w)));
+                const bool near = __builtin_fabsf(nv) <= T && __builtin_fabsf(rx - B.x) <= B.z + T && __builtin_fabsf(ry - B.y) <= B.w + T;
+                if (near && tri_fidx[idx + k] != self_tri) {
+                    if (c_n == 0u) c0 = idx + k; else if (c_n == 1u) c1 = idx + k; else if (c_n == 2u) c2 = idx + k;
+                    c_n = c_n < kPointCache ? c_n + 1u : kPointCacheBad;
+                }
+            }
+            nleaf += type;
+        }
+    }
+    nbox += 4;
+    node = next;
+    if (node == kNone && sp != 0u) { sp -= 1; node = lds_stack[(size_t)sp * kBvhThreads + tid]; }
+}
+
 // ---- the same two halves for a joint tree (128-byte nodes: 3-D nodes and footprint nodes, sphere and triangle leaves) ---------
 // A noted leaf is one word: bit 31 = triangle leaf, bits 28-30 = its records (1..6; a sphere leaf has 1), bits 0-27 = the first
 // record / leaf entry (the upload keeps a tree below 2^28 shapes).
