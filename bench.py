@@ -20,8 +20,8 @@ few scalars, the other legs as rows of numbers); the FULL record -- everything d
 (default gpurun_out/bench_detail_n<N>.json; the line names it in `detail`).
 
 At N = 1 with the default config the record also carries
-  other_configs   C3 full frame (at its named 64 spp) + the band rank 0 of 8 owns of C3, C4 and C5 + the C5 full frame, at a
-                  stated spp: rate + roofline each
+  other_configs   C3 full frame (at its named 64 spp) + the band rank 0 of 8 owns of C3, C4 and C5 + the C5 full frame + J1 (a joint
+                  tree: 5k spheres + 50k triangles, not a BASELINE config), at a stated spp: rate + roofline each
   lds_sweep       the LDS-staged f32-filter sweep BASELINE.json's configs[1] describes, same frame, same bits
   cpu_baseline    the CPU oracle on this host's cores, on a sub-sample of the SAME 1920x1080 view
 
@@ -80,6 +80,10 @@ CONFIGS = {
                name="10k random spheres (scene seed 1), 3840x2160"),
     "C5": dict(scene="triangles", n=1000000, seed=3, box=2.0, w=3840, h=2160, spp=256,
                name="1M random triangles (scene seed 3, box x2), 3840x2160, flat BVH"),
+    # not a BASELINE.json config: Scene.objects is an arbitrary mix (scene.rs:79-85, object.rs:9-15) and a scene with spheres AND a
+    # mesh walks a JOINT tree (wf_trace_packet_kernel<0>, trace_bvh_mesh_kernel<.,0,.>): this leg puts a rate and counters on that path
+    "J1": dict(scene="joint", n=55000, n_spheres=5000, n_tris=50000, seed=4, box=1.0, w=1920, h=1080, spp=8,
+               name="joint tree: 5k random spheres (seed 4) + 50k random triangles (seed 5), 1920x1080"),
 }
 KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 filter sweep + exact f64 (trace_mixed_kernel)",
                 3: "trace_mixed_kernel + verify",
@@ -96,8 +100,8 @@ KERNEL_NAMES = {1: "exact f64 sweep (trace_exact_kernel)", 2: "LDS-staged f32 fi
                    "launch, wf_trace_kernel + wf_shade_kernel per bounce level); the roofline object covers the whole sequence of "
                    "one launch, wf_trace_packet_kernel is ~55 % of it"}
 KERNEL_SHORT = {1: "trace_exact_kernel", 2: "trace_mixed_kernel (LDS sweep)", 3: "trace_mixed_kernel+verify",
-                4: "BVH: trace_sph_packet_kernel + trace_bvh_spheres_kernel", 5: "trace_bvh_mesh_kernel (regroup)",
-                6: "wavefront: wf_trace_packet_kernel + trace_bvh_mesh_kernel"}
+                4: "sphere tree: packets + per-lane walks", 5: "trace_bvh_mesh_kernel (regroup)",
+                6: "wavefront: packets + trace_bvh_mesh_kernel"}
 # substring of the rocprofv3 Kernel_Name rows that belong to a kernel id (RTX_KERNEL_BVH runs one of two kernels)
 KERNEL_SYMBOL = {1: ("trace_exact_kernel",), 2: ("trace_mixed_kernel",), 3: ("trace_mixed_kernel",),
                  4: ("trace_bvh_kernel", "trace_bvh_spheres_kernel", "trace_sph_packet_kernel"), 5: ("trace_bvh_regroup_kernel", "trace_bvh_mesh_kernel", "trace_bvh_spheres_pool_kernel"),
@@ -129,7 +133,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip C3 / C4 band / C5 band at N = 1")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect rocprofv3 counters in this run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of each cpu_baseline mode")
-    ap.add_argument("--other-spp", default="C3=64,C3band=64,C4=64,C5=1,C5band=4", help="rays per pixel of the other_configs legs")
+    ap.add_argument("--other-spp", default="C3=64,C3band=64,C4=64,C5=1,C5band=4,J1=8", help="rays per pixel of the other_configs legs")
     ap.add_argument("--detail-out", default=None,
                     help="file that receives the FULL record (per-kernel counters, every leg's roofline object, the log); default "
                          "gpurun_out/bench_detail_n<N>.json under the repo root.  stdout carries ONE compact line (< 2000 characters)")
@@ -147,6 +151,10 @@ def make_objects(cfg):
     from rust_raytracing_amd import scenes
     if cfg["scene"] == "spheres":
         return scenes.random_spheres(cfg["n"], cfg["seed"], box=cfg["box"])
+    if cfg["scene"] == "joint":                                  # spheres first: scene order decides ties (scene.rs:250)
+        import numpy as np
+        return np.concatenate([scenes.random_spheres(cfg["n_spheres"], cfg["seed"], box=cfg["box"]),
+                               scenes.random_triangles(cfg["n_tris"], cfg["seed"] + 1, box=cfg["box"])])
     return scenes.random_triangles(cfg["n"], cfg["seed"], box=cfg["box"])
 
 
@@ -202,7 +210,7 @@ def algorithmic(acc, cfg):
     """What the kernel counted in this run, priced in lane-instructions and bytes (unit = one ray segment)."""
     steps = max(acc.n, 1)
     seg = acc.segments / steps
-    tri = cfg["scene"] == "triangles"
+    tri = cfg["scene"] in ("triangles", "joint")                 # (a joint tree's leaf tests are priced as triangle tests: 10 of 11 shapes)
     out = {"segments_per_launch": seg / max(acc.launches / steps, 1)}
     if acc.kernel in (4, 5, 6):
         box, leaf, exact = acc.box / steps, (acc.filter - acc.box) / steps, acc.exact / steps
@@ -636,7 +644,7 @@ def cpu_baseline(seconds):
                   "segments per ray) through the f64 C restatement of the reference CPU path (the Rust crate cannot be built "
                   "here), clean mode: %d threads, no locks; linear scan over the 10^4 spheres per segment as the reference does "
                   "(scene.rs:243-251)" % (clean[5], clean[3], clean[4] / max(clean[3], 1), cores),
-        "sample_short": "every %dth row+column of the C2 1080p frame (%d px, 1 spp), C port of the CPU path, %d threads; ~%.0f s CPU" % (
+        "sample_short": "every %dth row+col of the C2 frame (%d px, 1 spp), C port of the CPU path, %d threads, %.0f s" % (
             clean[5], clean[3], cores, single[2] + clean[2] + fdt),
         "Msegments_s": clean[1], "segments_per_primary_ray": clean[4] / max(clean[3], 1), "seconds": single[2] + clean[2] + fdt,
         "clean_Mrays_s": clean[0], "faithful_Mrays_s": faithful[0], "faithful_Msegments_s": faithful[1],
@@ -772,7 +780,7 @@ def main():
         other_spp = dict(kv.split("=") for kv in args.other_spp.split(","))
         others = []
         full_rate = {}
-        for name, band in (("C3", False), ("C3", True), ("C4", True), ("C5", False), ("C5", True)):
+        for name, band in (("C3", False), ("C3", True), ("C4", True), ("C5", False), ("C5", True), ("J1", False)):
             oc = CONFIGS[name]
             s = int(other_spp.get(name + "band" if band and name + "band" in other_spp else name, 4))
             o_objs = objs if oc["scene"] == cfg["scene"] and oc["n"] == cfg["n"] and oc["seed"] == cfg["seed"] else make_objects(oc)

@@ -43,6 +43,22 @@ constexpr int kMeshStack = (RTX_MESH_WAVES <= 4 ? 39 : 160 / RTX_MESH_WAVES) - 1
 // = 35, needs no HBM column).  Measured, whole wavefront launch: C3 37.9 -> 36.1 ms at 3 (5: 43.8), C5 band level; a joint tree's
 // instance stays at 4 (240k axis-aligned faces: 166 ms at 4, 169 at 3); generating its own rays the kernel wants 4 (C5 band
 // alone: 72.3 ms at 4, 80.4 at 3, 89.6 at 5).
+// Segments that start on the triangle they left skip the walk (rtx_mesh_step.h, mesh_point_step).  Round 4's experiment, in the lab
+// library only: it removes 45 % of the exact tests, 7 % of the box tests and 15-20 % of the fabric traffic -- and no time, because the
+// traversal loop's iterations are set by the rays that LEAVE their triangle (C5: 4 % of the segments, 630 iterations each), beside
+// which the short self-hit walks ran in otherwise idle lanes (LAB_NOTEBOOK R4.5: C5 98.2 -> 101.5 ms, C3 35.8 -> 34.9 ms, same box).
+#ifndef RTX_MESH_POINT
+#ifdef RTX_LAB
+#define RTX_MESH_POINT 1
+#else
+#define RTX_MESH_POINT 0
+#endif
+#endif
+constexpr bool kMeshPoint = RTX_MESH_POINT != 0;
+#ifndef RTX_MESH_POINT_LANES
+#define RTX_MESH_POINT_LANES 1
+#endif
+constexpr uint32_t kMeshPointLanes = RTX_MESH_POINT_LANES;   // lanes that locate a point before their step runs (8 / 16 measured: slower)
 #ifndef RTX_MESH_WAVES_Q
 #define RTX_MESH_WAVES_Q 3
 #endif
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                 if constexpr (!PLAIN) { if (sv.bvh_flags & 1u) sphere_ray_from(sv, r.pos, r.dir, sr); }
                 tri_filter_from_ray(sv, r.pos, r.dir, tpar);
                 bool walk = true;
-                if constexpr (PLAIN == 2 && kSplit) {
+                if constexpr (PLAIN == 2 && kSplit && kMeshPoint) {
                     // a self-hit close enough for the point's set to decide it (t_self <= tau = tpar.A / 4): exact tests only, no walk
                     // -- after ONE point location per point, which runs in the traversal loop below (S_POINT)
                     if (h.id != kNone && left_tri != kNone && tpar.A < 1.0e29f && h.t <= (double)(tpar.A * 0.25f)) {
@@ -329,11 +345,13 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                     RTX_MPROF(4, lane == 0, 1)                              // traversal-loop iterations per wave
                     RTX_MPROF(5, state == S_TRAV, 1)                        // lanes walking in them
                     RTX_MPROF(6, state == S_POINT, 1)                       // lanes locating their point in them
-                    if constexpr (PLAIN == 2) {
+                    if constexpr (PLAIN == 2 && kMeshPoint) {
                         // the lanes that locate their point: one node each; a finished set sends its lane to its exact tests (or,
-                        // unusable, into the ordinary walk of this segment)
+                        // unusable, into the ordinary walk of this segment).  Like the leaf reads, the block runs when enough lanes
+                        // want it (or nobody walks): issued for one or two lanes in every iteration it cost more than the walks it saves
                         const bool pt = state == S_POINT;
-                        if (__ballot(pt) != 0ull) {
+                        const uint32_t n_pt = (uint32_t)__popcll(__ballot(pt));
+                        if (n_pt >= kMeshPointLanes || (n_pt != 0u && __ballot(state == S_TRAV) == 0ull)) {
                             if (pt) {
                                 mesh_point_step<STACKN>(nodes, ma, la.tri_fidx, (float)r.pos.x, (float)r.pos.y, tpar,
                                                         tpar.A + sv.bvh_origin_limit * 9.5367432e-7f, left_tri, node, sp, ls, tid, c_n, c0, c1, c2,

@@ -1384,7 +1384,7 @@ def test_bench_line_contract(gpu):
     """bench.py at a reduced sample count (counters off: they are the next test): one JSON line with the contract's keys,
     strong scaling by default, roofline objects that are fractions of a real ceiling for the value kernel, the LDS sweep
     and the three other configs, a cpu_baseline on the benchmark's own view, and the two kernels' frames bit-identical."""
-    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1,C5band=1", "--no-pmc",
+    d = _bench(["--steps", "1", "--warmup", "0", "--spp", "2", "--cpu-seconds", "1", "--other-spp", "C3=1,C3band=8,C4=2,C5=1,C5band=1,J1=1", "--no-pmc",
                 "--detail-out", "gpurun_out/test_bench_detail.json"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "other_configs", "lds_sweep"):
@@ -1407,15 +1407,15 @@ def test_bench_line_contract(gpu):
     assert d["lds_sweep"]["image_identical_to_value_kernel"] is True
     _check_roofline(d["lds_sweep"]["roofline"])
     assert d["speedup_vs_cpu"]["like_for_like_linear_scan"] > 10          # the LDS sweep scans the list as the CPU does
-    assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5", "C5"]
-    assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, False, True]
+    assert [o["config"] for o in d["other_configs"]] == ["C3", "C3", "C4", "C5", "C5", "J1"]
+    assert ["band" in o["workload"] for o in d["other_configs"]] == [False, True, True, False, True, False]
     # the stdout line: the contract's keys + roofline and cpu_baseline as objects, the other legs as rows of numbers
     ln = d["_line"]
     assert ln["detail"] == "gpurun_out/test_bench_detail.json"
     for key in ("value", "unit", "cores", "kind", "sample", "threads_started", "single_thread_Mrays_s"):
         assert key in ln["cpu_baseline"], key
     assert ln["cpu_baseline"]["kind"] == "port" and len(ln["roofline"]["stages"]) == 2
-    assert list(ln["other_configs"]) == ["C3", "C3band", "C4band", "C5", "C5band"]
+    assert list(ln["other_configs"]) == ["C3", "C3band", "C4band", "C5", "C5band", "J1"]
     assert all(len(row) == len(ln["other_cols"]) for row in ln["other_configs"].values())
     assert abs(ln["other_configs"]["C5"][0] - d["other_configs"][3]["value"]) <= 1e-3 * d["other_configs"][3]["value"]
     bal = d["partition_balance"]
