@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
     uint32_t qcnt = 0, nbox = 0, nleaf = 0, w_node = kNone, w_sp = 0;
     bool overflow = false, walked = false, midwalk = false;
 #if defined(RTX_LAB) && defined(RTX_SPH_PROFILE)
-    unsigned long long rtx_prof = 0;
+    unsigned long long rtx_prof = 0, t_prev = 0;
 #define RTX_PROF_PASS , rtx_prof
 #else
 #define RTX_PROF_PASS
@@ -211,6 +211,10 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
 
         // ---- one segment: closest_object (scene.rs:243-251).  Phase 1, f32 only: walk the tree, collect candidates.
         // A lane whose walk was cut (midwalk) comes back with its walk state and goes on where it left
+#if defined(RTX_LAB) && defined(RTX_SPH_PROFILE) && RTX_SPH_PROFILE >= 10
+        const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();       // lab build: where a wave's time goes (1/64 of the cycles, by lane 0)
+        if (RTX_SPH_PROFILE == 11 && lane == 0 && t_prev != 0ull) rtx_prof += (t_w0 - t_prev) >> 6;
+#endif
         const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
         if (!midwalk) { best_up = __builtin_inff(); qcnt = 0; nbox = 0; nleaf = 0; overflow = false; walked = false; w_node = kNone; w_sp = 0; }
         RayX rx;
@@ -257,6 +261,13 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_bvh_spher
             }
         }
         // ---- phase 2, f64: exact tests of the candidates that can still be the winner, the shapes outside the tree, ray_hit
+#if defined(RTX_LAB) && defined(RTX_SPH_PROFILE) && RTX_SPH_PROFILE >= 10
+        {
+            const unsigned long long t_w1 = __builtin_amdgcn_s_memtime();
+            if (RTX_SPH_PROFILE == 10 && lane == 0) rtx_prof += (t_w1 - t_w0) >> 6;        // the walk
+            t_prev = t_w1;                                                                   // 11: from here to the next walk (f64 phase + refill)
+        }
+#endif
 #if defined(RTX_LAB) && defined(RTX_SPH_PROFILE)
         {   // lab build: 1 f64 phases (rounds), 2 the exact loop's wave iterations (8: its lane iterations = exact tests + skipped entries)
             const unsigned long long fm = __ballot(alive && !midwalk);

@@ -825,7 +825,16 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_slots
     sr.px = sr.py = sr.pz = sr.dx = sr.dy = sr.dz = sr.Kg = sr.K = 0.f; sr.c0 = __builtin_inff();
     unsigned long long exact = 0;                                         // (an exhaustive fallback adds n_spheres at a time)
 
+#ifdef RTX_SLOT_PROFILE                      // lab build: where a wave's time goes (cycles / 64, by lane 0), through exact_tests
+    unsigned long long sp_prof = 0;
+#define RTX_SLOT_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime();
+#define RTX_SLOT_ACC(k, a, b) { if (RTX_SLOT_PROFILE == (k) && lane == 0) sp_prof += ((b) - (a)) >> 6; }
+#else
+#define RTX_SLOT_T(v)
+#define RTX_SLOT_ACC(k, a, b)
+#endif
     for (;;) {
+        RTX_SLOT_T(t_s0)
         // ---- lanes whose walk has ended leave their slot DONE (its candidates are in its LDS words already)
         {
             const bool fin = walking && node == kNone;
@@ -860,6 +869,8 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_slots
             idle_mask = __ballot(!walking);
             n_idle = (uint32_t)__popcll(idle_mask);
         }
+        RTX_SLOT_T(t_s1)
+        RTX_SLOT_ACC(3, t_s0, t_s1)
         // ---- the f64 phase, for up to 64 DONE slots (the head of the queue), when it runs full -- or the walk is starving
         if (n_done >= 64u || (n_done != 0u && n_ready == 0u && (n_idle == 64u || n_idle >= kSlotServe))) {
             const uint32_t take = n_done < 64u ? n_done : 64u;
@@ -1010,6 +1021,7 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_slots
 #ifndef RTX_SLOT_NOFENCE
             __threadfence_block();                                      // the records are read by other lanes of this wave, later
 #endif
+            { RTX_SLOT_T(t_s2) RTX_SLOT_ACC(2, t_s1, t_s2) }
             // free slots while the queue still has chunks are asked again; when it is empty they retired above, so a phase that
             // only re-queued free slots cannot repeat for ever
             continue;
@@ -1037,7 +1049,11 @@ __global__ __launch_bounds__(kBvhThreads, kSphWavesPerSimd) void trace_sph_slots
             const uint32_t n_fin = (uint32_t)__popcll(__ballot(walking && node == kNone));
             if (n_fin >= kSlotWait) break;
         }
+        { RTX_SLOT_T(t_s3) RTX_SLOT_ACC(1, t_s1, t_s3) }
     }
+#ifdef RTX_SLOT_PROFILE
+    exact = sp_prof;
+#endif
     unsigned long long box_tests = nbox, filt = (unsigned long long)nbox + nleaf, segs64 = segs;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
