@@ -940,7 +940,13 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         rv.n_rays = per_sample64 * ns;                      // (the padded tile grid when tiled)
         rv.tiles_x = tiles_x;
         {
-            const uint64_t per_wave = rv.n_rays / ((uint64_t)h->n_cus * 16u * 8u);       // 16 resident waves per CU
+            // grabs per wave: what is left in a wave's last grab when the queue runs dry is the launch's tail.  Measured on the band
+            // rank 0 of 8 owns of the C2 frame (1.67e7 rays, same box): 8: 7.33 ms, 16: 7.16, 32 and 64: 8.8 (a grab of 64 rays is one
+            // atomic per tile: the one address retires ~80 M adds per second); the full frame does not care (50.4 / 50.3 / 50.2 / 50.4)
+#ifndef RTX_GRABS_PER_WAVE
+#define RTX_GRABS_PER_WAVE 16
+#endif
+            const uint64_t per_wave = rv.n_rays / ((uint64_t)h->n_cus * 16u * RTX_GRABS_PER_WAVE);       // 16 resident waves per CU
             rv.grab = (uint32_t)(per_wave >= 512 ? 512 : (per_wave <= 64 ? 64 : (per_wave & ~(uint64_t)63)));
         }
         RTX_HIP_CHECK(hipMemcpyAsync(h->d_rv, &rv, sizeof(RowsView), hipMemcpyHostToDevice, stream));   // pageable: staged before return
