@@ -119,14 +119,19 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
 #if defined(RTX_LAB) && defined(RTX_MESH_PROFILE)      // lab build: one count per build, reported through exact_tests
     unsigned long long rtx_prof = 0;
 #define RTX_MPROF(k, cond, inc) { if (RTX_MESH_PROFILE == (k) && (cond)) rtx_prof += (inc); }
+#define RTX_MSTAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime();
+#define RTX_MTIME(k, a, b) { if (RTX_MESH_PROFILE == (k) && lane == 0) rtx_prof += ((b) - (a)) >> 6; }   // cycles / 64 of lane 0's wave
 #else
 #define RTX_MPROF(k, cond, inc)
+#define RTX_MSTAMP(v)
+#define RTX_MTIME(k, a, b)
 #endif
     for (;;) {
         // ================= the f64 phase (entered when the inner loop below finds it due) =================
         if (__ballot(state != S_IDLE) == 0ull && queue_empty) break;       // wave-uniform: nothing live, nothing left to take
         RTX_MPROF(1, lane == 0, 1)                                          // outer iterations (f64 phases) per wave
         RTX_MPROF(2, state == S_FIN || state == S_FLUSH, 1)                 // lanes served by them
+        RTX_MSTAMP(t_m0)
         if (state == S_FIN || state == S_FLUSH) {
             // ---- exact tests (sphere.rs:19-30, triangle.rs:108-127) of the candidates that can still be the winner
             const RayX rx = make_rayx(r.pos, r.dir);
@@ -189,6 +194,8 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                 }
             }
         }
+        RTX_MSTAMP(t_m1)
+        RTX_MTIME(9, t_m0, t_m1)                                            // cycles: exact tests + the rest of closest_object + ray_hit
         // ---- hand rays to idle lanes: ballot + prefix sum over the wave's local range, one atomic per rv.grab rays
         for (;;) {
             const unsigned long long idle_mask = __ballot(state == S_IDLE);
@@ -239,6 +246,8 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
             const unsigned long long taken = (unsigned long long)__popcll(idle_mask);
             wave_next = wave_next + taken < wave_end ? wave_next + taken : wave_end;
         }
+        RTX_MSTAMP(t_m2)
+        RTX_MTIME(10, t_m1, t_m2)                                           // cycles: refill
         // ---- set up the next segment
         RTX_MPROF(3, state == S_SETUP, 1)                                   // lanes set up
         if (state == S_SETUP) {
@@ -336,6 +345,8 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                 state = S_FIN;
             }
         }
+        RTX_MSTAMP(t_m3)
+        RTX_MTIME(11, t_m2, t_m3)                                           // cycles: set-up (self-hit pre-test, filter and slab parameters)
         // ================= traversal steps (f32 only) until the f64 phase is due again =================
         {
             float4 nd[MeshNode<PLAIN>::n];    // the node each TRAV lane opens next (the prefetched copy does not outlive this loop)
@@ -413,6 +424,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
                 if (waiting >= thresh || m_trav == 0ull) break;
             }
         }
+        { RTX_MSTAMP(t_m4) RTX_MTIME(12, t_m3, t_m4) }                        // cycles: the traversal loop
     }
 #if defined(RTX_LAB) && defined(RTX_MESH_PROFILE)
     exact = rtx_prof;
