@@ -310,9 +310,26 @@ int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t 
 /* Test hook: evaluates one f64 operation per element on the device (op 0: a/b, 1: sqrt(a),
  * 2: sin(a), 3: cos(a), 4 / 5: sincos(a)'s two results; 6: the packet walks' v_writelane -- out[i] = (int)b[0] in lane (int)b[1]
  * of every wave, (int)a[i] elsewhere; 7 / 8: v_min_f64 / v_max_f64 on the raw bits of a[i], b[i] -- the child sort's (key, link)
- * pairs are denormal f64 patterns when the key is +0.0 and must come back bit for bit); a, b, out are HOST arrays of n doubles.  Used by tests/ to check that the
+ * pairs are denormal f64 patterns when the key is +0.0 and must come back bit for bit; 9 / 10: the sin / cos the path itself uses
+ * for Vector3::random_direction's angle in [0, 2 pi] -- rtx_math.h sincos_2pi); a, b, out are HOST arrays of n doubles.  Used by tests/ to check that the
  * device's / and sqrt are correctly rounded and to measure how far its sin/cos are from libm. */
 int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n);
+
+/* Test hook (lab library; the product returns RTX_ERR_UNSUPPORTED): the TRANSCRIPT of every path of one image row, as the exhaustive
+ * f64 kernel (RTX_KERNEL_EXACT) walks it -- per segment the ray closest_object was asked about (scene.rs:232: position, direction),
+ * the winning distance and the winner's index in Scene.objects (scene.rs:243-251; -1 and +inf: no object, the path ends).  Images
+ * compare hit SEQUENCES (a colour is a product of materials); a transcript compares the arithmetic itself, every bounce direction
+ * and hit point to the last bit (tests: equal to the oracle's transcript when the oracle uses the device's sin / cos routine).
+ * steps: HOST array [width][rays_per_pixel][max_steps]; counts: HOST array [width][rays_per_pixel], the path's number of segments
+ * (steps beyond max_steps are counted, not stored). */
+typedef struct RtxPathStep {
+    double  position[3];
+    double  direction[3];
+    double  distance;
+    int64_t object;
+} RtxPathStep;
+int32_t rtx_debug_paths(RtxSceneHandle scene, uint32_t width, uint32_t height, uint32_t row, uint32_t max_steps,
+                        RtxPathStep *steps, uint32_t *counts);
 
 /* Test hook, needs no GPU: runs the host half of rtx_scene_upload (scene packing, filter records, the SAH build of
  * the flat BVH -- SURVEY 8f row N2; the reference's analogue is gpu_state.rs:53-77) and checks the tree's

@@ -5,6 +5,7 @@
  *
  * Citations are `path:line` relative to the reference's src/ directory.
  */
+#define _GNU_SOURCE                                   /* sincos() */
 #include "rtx_oracle.h"
 
 #include <math.h>
@@ -333,6 +334,8 @@ rtxo_vec3 rtxo_object_normal_at(const rtxo_object *o, rtxo_vec3 world_pos)      
 typedef struct {
     const rtxo_scene *scene;
     pthread_mutex_t  *locks;      /* NULL in clean mode */
+    rtxo_path_step   *steps;      /* NULL, or where ctx_render_ray writes the current path's transcript (rtxo_trace_row) */
+    uint32_t          max_steps, *n_steps;
 } render_ctx;
 
 static inline int ctx_distance(const render_ctx *c, uint64_t i, rtxo_vec3 pos, rtxo_vec3 dir, double *dst)
@@ -360,12 +363,66 @@ static inline rtxo_vec3 ctx_normal_at(const render_ctx *c, uint64_t i, rtxo_vec3
 /* ------------------------------------------------------------------------------------------- */
 /* Shading + bounce loop (raytracing/scene.rs)                                                   */
 /* ------------------------------------------------------------------------------------------- */
+/* sin / cos of random_direction's angle.  Mode 0 (the default, and what the reference does): the platform libm, f64::cos / f64::sin
+ * (vector.rs:40-41).  Mode 1 -- a test mode, not the reference: the routine the DEVICE uses for this angle (the product's
+ * rtx_math.h sincos_2pi, restated here operation for operation: fdlibm's medium-argument reduction and __kernel_sin / __kernel_cos).
+ * No two libms agree on the last bit of sin / cos, so that is the one place the device may differ from this oracle (<= 1 ulp, images
+ * within 1e-9); with mode 1 the difference is gone and the kernels must equal the oracle BIT FOR BIT, which turns every seeded
+ * comparison of the test suite into an exact one (tests/test_gpu_parity.py). */
+static int g_sincos_mode = 0;
+void rtxo_set_sincos_mode(int mode) { g_sincos_mode = mode; }
+
+void rtxo_device_sincos(double x, double *sn, double *cs)
+{
+    static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                        pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21,
+                        pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;
+    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                        S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                        C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double fn = rint(x * invpio2);
+    double r = x - fn * pio2_1, w, t;
+    t = r; w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
+    t = r; w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
+    const double y0 = r - w, y1 = (r - y0) - w;
+    const double z = y0 * y0, v = z * y0;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs(y0);
+    uint64_t hb;
+    memcpy(&hb, &ax, sizeof hb);
+    hb = (hb & 0xFFFFFFFF00000000ULL) - 0x0020000000000000ULL;
+    double qx;
+    memcpy(&qx, &hb, sizeof qx);
+    qx = ax > 0.78125 ? 0.28125 : qx;
+    qx = ax < 0.3 ? 0.0 : qx;
+    const double hz = 0.5 * z - qx, a = 1.0 - qx;
+    const double c = a - (hz - (z * rc - y0 * y1));
+    const int n = (int)fn & 3;
+    *sn = n == 0 ? s : (n == 1 ? c : (n == 2 ? -s : -c));
+    *cs = n == 0 ? c : (n == 1 ? -s : (n == 2 ? -c : s));
+}
+
+void rtxo_device_sincos_n(const double *x, size_t n, double *sn, double *cs)
+{
+    for (size_t i = 0; i < n; ++i) rtxo_device_sincos(x[i], sn + i, cs + i);
+}
+
 rtxo_vec3 rtxo_random_direction(double u_z, double u_theta)         /* vector.rs:36-45 */
 {
     double z = u_z * 2.0 - 1.0;
     double theta = u_theta * 2.0 * 3.14159265358979323846;          /* std::f64::consts::PI */
     double r = sqrt(1.0 - z * z);
-    return rtxo_norm(v3(r * cos(theta), r * sin(theta), z));
+    if (g_sincos_mode == 1) {
+        double sn, cs;
+        rtxo_device_sincos(theta, &sn, &cs);
+        return rtxo_norm(v3(r * cs, r * sn, z));
+    }
+    double sn, cs;
+    sincos(theta, &sn, &cs);                                        /* (see rtxo_get_ray_dir: one glibc sincos call, by name) */
+    return rtxo_norm(v3(r * cs, r * sn, z));
 }
 
 rtxo_vec3 rtxo_random_bounce_dir(rtxo_vec3 ray_dir, rtxo_vec3 surface_normal, double surface_roughness,
@@ -410,7 +467,7 @@ static int64_t ctx_closest_object(const render_ctx *c, rtxo_vec3 pos, rtxo_vec3 
 
 int64_t rtxo_closest_object(const rtxo_scene *s, rtxo_vec3 pos, rtxo_vec3 dir, double *dst)
 {
-    render_ctx c = { s, NULL };
+    render_ctx c = { s, NULL, NULL, 0, NULL };
     return ctx_closest_object(&c, pos, dir, dst);
 }
 
@@ -418,7 +475,14 @@ rtxo_vec3 rtxo_get_ray_dir(const rtxo_scene *s, double x, double y, double verti
 {
     double angle_x = s->camera.fov * (x - 0.5);
     double angle_y = vertical_fov * (y - 0.5);
-    rtxo_vec3 cam_space_dir = v3(sin(angle_x), sin(angle_y), cos(angle_x) * cos(angle_y));
+    /* f64::sin and f64::cos of one angle (scene.rs:216-219): on a GNU target the compiler makes ONE glibc sincos() call of such a
+     * pair (LLVM for the reference's rustc build, gcc for this file -- it did, before this was spelled out), and glibc's sincos
+     * differs from its sin / cos in the last place on ~0.07 % of arguments (2.35).  Called by name here and in random_direction so
+     * that the oracle does not depend on the optimiser's mood; the product's host tables call the same function. */
+    double sx, cx, sy, cy;
+    sincos(angle_x, &sx, &cx);
+    sincos(angle_y, &sy, &cy);
+    rtxo_vec3 cam_space_dir = v3(sx, sy, cx * cy);
     return rtxo_camera_rotate_to_world_space(&s->camera, cam_space_dir);
 }
 
@@ -437,6 +501,16 @@ static rtxo_vec3 ctx_render_ray(const render_ctx *c, ray_t ray, uint64_t key, ui
         double dst;
         if (segments) ++*segments;
         int64_t hit = ctx_closest_object(c, ray.position, ray.direction, &dst);
+        if (c->steps) {
+            if (*c->n_steps < c->max_steps) {
+                rtxo_path_step *st = &c->steps[*c->n_steps];
+                st->position[0] = ray.position.x; st->position[1] = ray.position.y; st->position[2] = ray.position.z;
+                st->direction[0] = ray.direction.x; st->direction[1] = ray.direction.y; st->direction[2] = ray.direction.z;
+                st->distance = hit < 0 ? INFINITY : dst;
+                st->object = hit;
+            }
+            ++*c->n_steps;
+        }
         if (hit < 0)
             break;
         ray.position = vadd(ray.position, vmuls(ray.direction, dst));  /* scene.rs:234 */
@@ -480,7 +554,14 @@ static rtxo_vec3 ctx_render_pixel(const render_ctx *c, double u, double v, doubl
         rtxo_vec3 ray_direction = vsub(target_point, ray_position);                                /* scene.rs:205 */
         ray.position = ray_position;
         ray.direction = rtxo_norm(ray_direction);                                                 /* scene.rs:207 */
-        rtxo_vec3 col = ctx_render_ray(c, ray, key, &draw, segments);
+        render_ctx cs = *c;
+        uint32_t n_steps = 0;
+        if (c->steps) {                                             /* rtxo_trace_row: this sample's slice of the row's transcript */
+            cs.steps = c->steps + sample * c->max_steps;
+            cs.n_steps = &n_steps;
+        }
+        rtxo_vec3 col = ctx_render_ray(&cs, ray, key, &draw, segments);
+        if (c->steps) c->n_steps[sample] = n_steps;
         sum = vadd(sum, col);
     }
     return vdivs(sum, (double)n);                                   /* scene.rs:253-259: sum / len */
@@ -489,8 +570,25 @@ static rtxo_vec3 ctx_render_pixel(const render_ctx *c, double u, double v, doubl
 rtxo_vec3 rtxo_render_pixel(const rtxo_scene *s, double u, double v, double vertical_fov,
                             uint64_t pixel_index, uint64_t *segments)
 {
-    render_ctx c = { s, NULL };
+    render_ctx c = { s, NULL, NULL, 0, NULL };
     return ctx_render_pixel(&c, u, v, vertical_fov, pixel_index, segments);
+}
+
+/* The transcript of every path of one image row (test aid; the lab library's rtx_debug_paths is the device's): per segment the ray
+ * closest_object was asked about, the winning distance and object index (-1, +inf: none).  steps [width][rays_per_pixel][max_steps],
+ * counts [width][rays_per_pixel]. */
+int rtxo_trace_row(const rtxo_scene *s, uint32_t width, uint32_t height, uint32_t row, uint32_t max_steps,
+                   rtxo_path_step *steps, uint32_t *counts)
+{
+    if (!s || !steps || !counts || row >= height || width == 0 || max_steps == 0) return -1;
+    const double vertical_fov = (double)height / (double)width * s->camera.fov;     /* scene.rs:145 */
+    const double y = (double)row / (double)height;
+    const uint64_t spp = s->config.rays_per_pixel;
+    for (uint32_t xi = 0; xi < width; ++xi) {
+        render_ctx c = { s, NULL, steps + (uint64_t)xi * spp * max_steps, max_steps, counts + (uint64_t)xi * spp };
+        (void)ctx_render_pixel(&c, (double)xi / (double)width, y, vertical_fov, (uint64_t)row * width + xi, NULL);
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------- */

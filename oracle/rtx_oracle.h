@@ -24,6 +24,7 @@
 #ifndef RTX_ORACLE_H
 #define RTX_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -73,6 +74,17 @@ enum { RTXO_MODE_CLEAN = 0, RTXO_MODE_FAITHFUL = 1 };
 /* --- counter-based RNG shared bit-for-bit with the HIP kernel ------------------------------- */
 uint64_t rtxo_rng_key(uint64_t seed, uint64_t pixel_index, uint64_t sample_index);
 double   rtxo_rng_u01(uint64_t key, uint64_t draw_index);      /* fastrand::f64() distribution */
+typedef struct rtxo_path_step {                      /* one segment of a path's transcript (rtxo_trace_row) */
+    double  position[3], direction[3], distance;
+    int64_t object;
+} rtxo_path_step;
+int      rtxo_trace_row(const rtxo_scene *s, uint32_t width, uint32_t height, uint32_t row, uint32_t max_steps,
+                        rtxo_path_step *steps, uint32_t *counts);
+/* random_direction's sin / cos (vector.rs:40-41): 0 = the platform libm (the reference; default), 1 = the routine the device uses for
+ * that angle (a test mode: the kernels then equal this oracle bit for bit).  Process-wide; set it before rendering. */
+void     rtxo_set_sincos_mode(int mode);
+void     rtxo_device_sincos(double x, double *sn, double *cs);
+void     rtxo_device_sincos_n(const double *x, size_t n, double *sn, double *cs);
 
 /* --- math (src/math) ------------------------------------------------------------------------ */
 double    rtxo_dot(rtxo_vec3 a, rtxo_vec3 b);                    /* vector.rs:85-87 */

@@ -103,6 +103,14 @@ def lib():
         getattr(L, name).argtypes = [dp, V]
     L.rtxo_triangle_contains.restype = C.c_int
     L.rtxo_triangle_contains.argtypes = [dp, V]
+    L.rtxo_set_sincos_mode.restype = None
+    L.rtxo_set_sincos_mode.argtypes = [C.c_int]
+    L.rtxo_device_sincos.restype = None
+    L.rtxo_device_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rtxo_trace_row.restype = C.c_int
+    L.rtxo_trace_row.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.rtxo_device_sincos_n.restype = None
+    L.rtxo_device_sincos_n.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.rtxo_random_direction.restype = V
     L.rtxo_random_direction.argtypes = [C.c_double, C.c_double]
     L.rtxo_random_bounce_dir.restype = V
@@ -174,6 +182,17 @@ def triangle_normal(v0, v1, v2):
     return lib().rtxo_triangle_normal(g, Vec3(0, 0, 0)).tuple()
 
 
+def closest_object(scene, pos, direction):
+    """(index, distance) of Scene::closest_object (scene.rs:243-251); (-1, None) when nothing is hit."""
+    d = C.c_double()
+    i = lib().rtxo_closest_object(C.byref(scene), vec(pos), vec(direction), C.byref(d))
+    return (int(i), d.value) if i >= 0 else (-1, None)
+
+
+def random_direction(u_z, u_theta):
+    return lib().rtxo_random_direction(float(u_z), float(u_theta)).tuple()
+
+
 def random_bounce_dir(ray_dir, normal, roughness, u_z, u_theta):
     return lib().rtxo_random_bounce_dir(vec(ray_dir), vec(normal), float(roughness),
                                         float(u_z), float(u_theta)).tuple()
@@ -208,6 +227,22 @@ def render(scene, width, height, n_threads=None, mode=MODE_CLEAN, row_begin=0, r
     return (out, seg) if want_segments else out
 
 
+PATH_STEP_DTYPE = np.dtype([("position", "<f8", (3,)), ("direction", "<f8", (3,)), ("distance", "<f8"), ("object", "<i8")])
+
+
+def trace_row(scene, width, height, row, max_steps):
+    """(steps, counts): the transcript of every path of image row `row` -- per segment the ray closest_object was asked about
+    (scene.rs:232), the winning distance and object index (-1, inf: none).  steps [width][rays_per_pixel][max_steps], counts
+    [width][rays_per_pixel]."""
+    spp = int(scene.config.rays_per_pixel)
+    steps = np.zeros((int(width), spp, int(max_steps)), dtype=PATH_STEP_DTYPE)
+    counts = np.zeros((int(width), spp), dtype=np.uint32)
+    rc = lib().rtxo_trace_row(C.byref(scene), int(width), int(height), int(row), int(max_steps), steps.ctypes.data, counts.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("rtxo_trace_row failed: %d" % rc)
+    return steps, counts
+
+
 def render_pixels(scene, width, height, xs, ys, n_threads=None, want_segments=False):
     """img[ys[k]][xs[k]] of Scene::render's width x height frame for a list of pixels -> (n, 3) float64
     (and (n,) uint64 closest_object counts)."""
@@ -231,3 +266,29 @@ def quantize_image(rgb):
     out = np.zeros((h, w, 3), dtype=np.uint8)
     lib().rtxo_quantize_image(rgb.ctypes.data, w, h, out.ctypes.data)
     return out
+
+
+def set_device_sincos(on):
+    """random_direction's sin / cos: False = libm (the reference, default), True = the device's routine (the kernels then equal the
+    oracle bit for bit).  Process-wide."""
+    lib().rtxo_set_sincos_mode(1 if on else 0)
+
+
+class device_sincos:
+    """with oracle.device_sincos(): ...   -- the oracle computes random_direction's sin / cos as the device does, inside the block."""
+
+    def __enter__(self):
+        set_device_sincos(True)
+        return self
+
+    def __exit__(self, *exc):
+        set_device_sincos(False)
+        return False
+
+
+def device_sincos_values(x):
+    """(sin, cos) arrays of the device's routine evaluated on the CPU (bit-identical arithmetic)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    lib().rtxo_device_sincos_n(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data)
+    return s, c

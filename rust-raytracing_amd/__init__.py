@@ -362,6 +362,7 @@ class SceneHandle:
         self.lab = scene.config.wants_lab() if lab is None else bool(lab)
         self._lib = load_library(self.lab)
         self.device = int(device)
+        self.rays_per_pixel = int(scene.config.rays_per_pixel)
         self._h = C.c_void_p()
         packed = scene.packed()
         sc = _scene_c(scene.config, scene.camera, packed)
@@ -375,6 +376,7 @@ class SceneHandle:
             raise ValueError("this handle lives in the product library; a lab config needs scene.upload(lab=True)")
         c = config.to_c()
         self._check(self._lib.rtx_scene_set_config(self._h, C.byref(c)))
+        self.rays_per_pixel = int(config.rays_per_pixel)
 
     def set_scratch_limit(self, n_bytes):
         """Upper bound of the handle's per-render scratch (0 = default); larger frames are traced in sample batches, same bits."""
@@ -389,6 +391,16 @@ class SceneHandle:
         arr = packed if isinstance(packed, np.ndarray) else pack_objects(packed)
         arr = np.ascontiguousarray(arr, dtype=OBJECT_DTYPE)
         self._check(self._lib.rtx_scene_append_objects(self._h, arr.ctypes.data, len(arr)))
+
+    def debug_paths(self, width, height, row, max_steps):
+        """(steps, counts) -- the transcript of every path of image row `row` as the exhaustive f64 kernel walks it (rtx_debug_paths;
+        a lab-library hook: upload with lab=True).  steps: structured array [width][rays_per_pixel][max_steps] of PATH_STEP_DTYPE,
+        counts: uint32 [width][rays_per_pixel]."""
+        spp = self.rays_per_pixel
+        steps = np.zeros((int(width), spp, int(max_steps)), dtype=PATH_STEP_DTYPE)
+        counts = np.zeros((int(width), spp), dtype=np.uint32)
+        self._check(self._lib.rtx_debug_paths(self._h, int(width), int(height), int(row), int(max_steps), steps.ctypes.data, counts.ctypes.data))
+        return steps, counts
 
     def render_rows(self, width, height, row_begin, row_stride, n_rows, d_out_ptr, stream=None, want_stats=True):
         """d_out_ptr: device address of n_rows*width*3 doubles (e.g. a torch tensor's data_ptr())."""
@@ -433,6 +445,10 @@ def debug_host_scene(scene):
     stats = (C.c_uint64 * 16)()
     abi.check(load_library().rtx_debug_host_scene(C.byref(sc), stats))
     return dict(zip(HOST_SCENE_STATS, (int(v) for v in stats)))
+
+
+# one segment of a path's transcript (RtxPathStep, include/rtx_hip.h)
+PATH_STEP_DTYPE = np.dtype([("position", "<f8", (3,)), ("direction", "<f8", (3,)), ("distance", "<f8"), ("object", "<i8")])
 
 
 def debug_math(op, a, b=None):

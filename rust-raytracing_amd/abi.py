@@ -93,6 +93,7 @@ SYMBOLS = [
                                       C.c_void_p, C.c_void_p, C.POINTER(RtxStats)]),
     ("rtx_quantize_image_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
     ("rtx_debug_math", C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("rtx_debug_paths", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("rtx_debug_host_scene", C.c_int32, [C.POINTER(RtxScene), C.POINTER(C.c_uint64)]),
 ]
 

@@ -92,6 +92,7 @@ struct RtxSceneHandle_ {
     void *wf_state = nullptr;   size_t wf_bytes = 0;       // the wavefront kernels' ray state
     void *pool = nullptr;       size_t pool_bytes = 0;     // (lab) the pool / pair forms of the sphere kernel's stage 2
     void *slots = nullptr;      size_t slots_bytes = 0;    // the slot records of the sphere kernel's stage 2 (trace_sph_slots_kernel)
+    PathStep *transcript = nullptr; uint32_t *transcript_counts = nullptr; uint32_t transcript_steps = 0;   // (lab) rtx_debug_paths, set for one call
     Counters *counters = nullptr;
     unsigned long long *work_counter = nullptr;
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
@@ -810,7 +811,12 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         if (batch > fit32) batch = fit32;
     }
 
-    // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row
+    // ---- trig tables of get_ray_dir (scene.rs:213-220), host libm, one value per column / local row.
+    // glibc's sincos(), called by name: the reference takes f64::sin and f64::cos of the same angle, and a compiler on a GNU target
+    // turns such a pair into ONE sincos call (LLVM does for rustc's output, gcc does for the test suite's CPU checker) -- whose results
+    // differ from sin() / cos() in the last place on ~0.07 % of arguments (glibc 2.35).  Left to the optimiser, this code had one loop
+    // merged and one not: one image row in ~100 started its primary rays an ulp off the CPU's (found by the path transcripts,
+    // rtx_debug_paths).  Spelled out, both sides call the same function whatever the optimiser does.
     const size_t tdbl = 2 * (size_t)width + 2 * (size_t)n_rows;
     const bool t_same = h->t_valid && h->t_w == width && h->t_h == height && h->t_rb == row_begin &&
                         h->t_rs == row_stride && h->t_blk == row_block && h->t_nr == n_rows && h->t_fov == h->cam.fov;
@@ -833,13 +839,13 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         for (uint32_t x = 0; x < width; ++x) {
             double u = (double)x / (double)width;                                       // scene.rs:157
             double angle_x = fov * (u - 0.5);                                           // scene.rs:214
-            sx[x] = std::sin(angle_x); cx[x] = std::cos(angle_x);
+            ::sincos(angle_x, &sx[x], &cx[x]);
         }
         for (uint32_t k = 0; k < n_rows; ++k) {
             const uint32_t kb = k / row_block;
             double v = (double)(row_begin + kb * row_stride + (k - kb * row_block)) / (double)height;   // scene.rs:153 (image_row)
             double angle_y = vertical_fov * (v - 0.5);                                  // scene.rs:215
-            sy[k] = std::sin(angle_y); cy[k] = std::cos(angle_y);
+            ::sincos(angle_y, &sy[k], &cy[k]);
         }
         RTX_HIP_CHECK(hipMemcpyAsync(h->tables, h->h_tables, tdbl * sizeof(double), hipMemcpyHostToDevice, stream));
         h->t_w = width; h->t_h = height; h->t_rb = row_begin; h->t_rs = row_stride; h->t_blk = row_block; h->t_nr = n_rows;
@@ -953,6 +959,10 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
         if (kernel == RTX_KERNEL_EXACT) {
             RTX_HIP_CHECK(launch_trace_exact(h->d_sv, h->d_rv, rv, h->samples, h->counters, stream));
+#ifdef RTX_LAB
+            if (h->transcript)
+                RTX_HIP_CHECK(launch_trace_transcript(h->d_sv, h->d_rv, rv, h->transcript, h->transcript_counts, h->transcript_steps, stream));
+#endif
         } else if (kernel == RTX_KERNEL_WAVEFRONT) {
 #ifdef RTX_LAB
             if (!wf_mesh)
@@ -1387,6 +1397,45 @@ int32_t rtx_debug_host_scene(const RtxScene *scene, uint64_t *stats)
     if ((p.sv.bvh_flags & 1u) && stats[8] != p.spheres.size()) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: a sphere is in no leaf");
     if ((p.sv.bvh_flags & 2u) && stats[9] != p.sv.n_tri_tree) return fail(RTX_ERR_INVALID_ARGUMENT, "bvh check: a triangle is in no leaf");
     return RTX_OK;
+}
+
+int32_t rtx_debug_paths(RtxSceneHandle h, uint32_t width, uint32_t height, uint32_t row, uint32_t max_steps, RtxPathStep *steps,
+                        uint32_t *counts)
+{
+#ifdef RTX_LAB
+    static_assert(sizeof(RtxPathStep) == sizeof(PathStep) && sizeof(PathStep) == 64, "RtxPathStep layout");
+    if (!h || !steps || !counts) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_paths: null argument");
+    if (width == 0 || row >= height || max_steps == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_paths: bad row / size");
+    const uint64_t paths = (uint64_t)width * h->cfg.rays_per_pixel;
+    if (paths == 0) return RTX_OK;
+    if (paths * max_steps > (1ull << 24)) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_paths: more than 2^24 steps asked for");
+    RTX_HIP_CHECK(hipSetDevice(h->device));
+    struct Bufs {                                   // freed, and the handle's pointers cleared, on every return path
+        RtxSceneHandle_ *h; double *rgb = nullptr; uint32_t kernel;
+        ~Bufs() {
+            (void)hipDeviceSynchronize();
+            if (h->transcript) (void)hipFree(h->transcript);
+            if (h->transcript_counts) (void)hipFree(h->transcript_counts);
+            if (rgb) (void)hipFree(rgb);
+            h->transcript = nullptr; h->transcript_counts = nullptr; h->transcript_steps = 0; h->cfg.kernel = kernel;
+        }
+    } d{h, nullptr, h->cfg.kernel};
+    RTX_HIP_CHECK(hipMalloc((void **)&h->transcript, paths * max_steps * sizeof(PathStep)));
+    RTX_HIP_CHECK(hipMalloc((void **)&h->transcript_counts, paths * sizeof(uint32_t)));
+    RTX_HIP_CHECK(hipMalloc((void **)&d.rgb, (size_t)width * 3 * sizeof(double)));
+    RTX_HIP_CHECK(hipMemset(h->transcript, 0, paths * max_steps * sizeof(PathStep)));
+    h->transcript_steps = max_steps;
+    h->cfg.kernel = RTX_KERNEL_EXACT;
+    RtxStats st;
+    if (int32_t rc = render_band(h, width, height, row, 1u, 1u, 1u, d.rgb, nullptr, &st)) return rc;
+    if (st.trace_launches != 1) return fail(RTX_ERR_UNSUPPORTED, "rtx_debug_paths: the row did not fit one launch");
+    RTX_HIP_CHECK(hipMemcpy(steps, h->transcript, paths * max_steps * sizeof(PathStep), hipMemcpyDeviceToHost));
+    RTX_HIP_CHECK(hipMemcpy(counts, h->transcript_counts, paths * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RTX_OK;
+#else
+    (void)h; (void)width; (void)height; (void)row; (void)max_steps; (void)steps; (void)counts;
+    return fail(RTX_ERR_UNSUPPORTED, "rtx_debug_paths: a lab-library hook (librtx_hip_lab.so)");
+#endif
 }
 
 int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n)

@@ -115,6 +115,13 @@ RTX_HD uint32_t image_row(const RowsView &rv, uint32_t k)
     return rv.row_begin + b * rv.row_stride + (k - b * rv.row_block);
 }
 
+// One segment of a path's transcript (rtx_debug_paths, lab library): the ray as closest_object saw it, the winning distance and the
+// winner's index in Scene.objects (-1 and +inf: the ray left the scene).  Same layout as RtxPathStep (include/rtx_hip.h).
+struct PathStep {
+    double pos[3], dir[3], t;
+    long long object;
+};
+
 // Sharded counters (one slot per wave-id hash) summed on the host.
 struct Counters {
     unsigned long long segments;
@@ -217,7 +224,7 @@ __device__ __forceinline__ V3 random_direction(double u_z, double u_theta)
     double theta = u_theta * 2.0 * 3.14159265358979323846;
     double r = sqrt(1.0 - z * z);
     double sn, cs;
-    sincos(theta, &sn, &cs);
+    sincos_2pi(theta, &sn, &cs);                                   // (rtx_math.h: theta is in [0, 2 pi))
     return vnorm(mk(r * cs, r * sn, z));
 }
 

@@ -115,6 +115,59 @@ __global__ __launch_bounds__(256) void trace_exact_kernel(const SceneView *__res
     flush_counters(ctr, segs, segs * sv.n_objects, 0);
 }
 
+#ifdef RTX_LAB
+// The EXACT kernel's loop once more, writing every segment down (rtx_debug_paths): step b of the path of local pixel pl, sample s
+// goes to steps[(pl * n_samples + s) * max_steps + b] while b < max_steps; counts[] takes the path's number of segments.
+__global__ __launch_bounds__(256) void trace_transcript_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
+                                                               PathStep *__restrict__ steps, uint32_t *__restrict__ counts, uint32_t max_steps)
+{
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rv.n_rays) return;
+    uint32_t pl, s_local;
+    ray_index_to_pixel(rv, i, pl, s_local);
+    RayState r;
+    gen_primary(sv, rv, pl, rv.sample_begin + s_local, r);
+    PathStep *out = steps + ((size_t)pl * rv.n_samples + s_local) * max_steps;
+    uint32_t n = 0;
+    if (sv.n_objects != 0) {
+        const uint64_t limit = sv.max_bounces + 1;
+        for (uint64_t b = 0; b < limit; ++b) {
+            if (light_is_zero(r)) break;
+            RayX rx = make_rayx(r.pos, r.dir);
+            Hit h;
+            hit_init(h);
+            closest_spheres_exact(sv, rx, h);
+            closest_planes_exact(sv, rx, h);
+            closest_tris_exact(sv, rx, h);
+            const bool miss = h.id == 0xFFFFFFFFu;
+            if (n < max_steps) {
+                PathStep st;
+                st.pos[0] = r.pos.x; st.pos[1] = r.pos.y; st.pos[2] = r.pos.z;
+                st.dir[0] = r.dir.x; st.dir[1] = r.dir.y; st.dir[2] = r.dir.z;
+                st.t = miss ? __builtin_inf() : h.t;
+                st.object = miss ? -1ll : (long long)h.id;
+                out[n] = st;
+            }
+            ++n;
+            if (miss) break;
+            advance_and_shade(sv, h, r);
+        }
+    }
+    counts[(size_t)pl * rv.n_samples + s_local] = n;
+}
+
+hipError_t launch_trace_transcript(const SceneView *d_sv, const RowsView *d_rv, const RowsView &rv, PathStep *steps, uint32_t *counts,
+                                   uint32_t max_steps, hipStream_t stream)
+{
+    if (rv.n_rays == 0) return hipSuccess;
+    if (rv.n_rays > (1ull << 30)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(trace_transcript_kernel, dim3((uint32_t)((rv.n_rays + 255) / 256)), dim3(256), 0, stream, d_sv, d_rv, steps, counts, max_steps);
+    return hipGetLastError();
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // MIXED kernel
 // ------------------------------------------------------------------------------------------
@@ -560,6 +613,7 @@ __global__ void debug_math_kernel(int op, const double *a, const double *b, doub
         case 6:                                          // rtx_writelane (rtx_traverse.h): lane (int)b[1] of every wave takes (int)b[0]
             r = (double)rtx_writelane(__builtin_amdgcn_readfirstlane((int)b[0]), __builtin_amdgcn_readfirstlane((int)b[1]), (int)a[i]);
             break;
+        case 9: case 10: { double sn, cs; sincos_2pi(a[i], &sn, &cs); r = (op == 9) ? sn : cs; } break;     // random_direction's sin / cos (rtx_math.h)
         default: {                                       // 7 / 8: the child sort's v_min_f64 / v_max_f64 on raw bit patterns
             double lo, hi;
             rtx_minmax_f64_bits(a[i], b[i], lo, hi);

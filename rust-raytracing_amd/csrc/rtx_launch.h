@@ -137,6 +137,10 @@ hipError_t launch_quantize_values(const double *rgb, uint8_t *rgb8, uint64_t n, 
 
 // device evaluation of single f64 ops (tests: are / and sqrt correctly rounded, how far are sin/cos)
 // op: 0 a/b, 1 sqrt(a), 2 sin(a), 3 cos(a)
+#ifdef RTX_LAB
+hipError_t launch_trace_transcript(const SceneView *d_sv, const RowsView *d_rv, const RowsView &rv, PathStep *steps, uint32_t *counts,
+                                   uint32_t max_steps, hipStream_t stream);
+#endif
 hipError_t launch_debug_math(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
 
 }  // namespace rtx

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 #define RTX_HD __host__ __device__ __forceinline__
 
@@ -78,6 +79,58 @@ RTX_HD double rng_u01(uint64_t key, uint32_t draw_index)              // fastran
     __builtin_memcpy(&d, &bits, sizeof d);
     return d - 1.0;
 #endif
+}
+
+// sin and cos of an angle in [0, 2 pi] -- Vector3::random_direction's theta = u * 2 * pi (vector.rs:38-42), the path's only
+// transcendental call.  The reference calls the platform libm; no two libms agree on the last bit of sin / cos, so this is where the
+// device was always allowed to differ (tests: <= 1 ulp from glibc; images within 1e-9).  The device library's sincos() is a general
+// routine (Payne-Hanek reduction for any argument: ~175 instructions in a phase that is issue-bound); for this range fdlibm's
+// medium-argument path does: n = rint(x * 2/pi) in 0..4, x - n * pi/2 in three exact-product steps (33 + 33 + 53 bits of pi/2:
+// a 118-bit pi/2, so arguments next to a multiple of pi/2 keep their relative accuracy), then fdlibm's __kernel_sin / __kernel_cos
+// polynomials on [-pi/4, pi/4] with the reduction's tail (each < 1 ulp), and the quadrant's swap / signs.  77 instructions.
+// Plain mul / add in fdlibm's order (no contraction), so the same operations on a CPU give the same bits: the test suite's CPU
+// checker has a mode that restates this routine, and then the kernels must equal it bit for bit (tests/test_gpu_parity.py).
+RTX_HD void sincos_2pi(double x, double *sn, double *cs)
+{
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21,
+                 pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double fn = rint(x * invpio2);
+    double r = x - fn * pio2_1, w, t;                                   // (fn * pio2_1 is exact: 3 x 33 bits)
+    t = r; w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
+    t = r; w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
+    const double y0 = r - w, y1 = (r - y0) - w;                         // the reduced argument and its tail
+    const double z = y0 * y0, v = z * y0;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);    // __kernel_sin(y0, y1, 1)
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs(y0);
+    // __kernel_cos's qx: 0 below 0.3, |x| / 4 with the low word cleared up to 0.78125, 0.28125 above
+    double axd = ax;
+    uint64_t hb;
+#if defined(__HIP_DEVICE_COMPILE__)
+    hb = (uint64_t)__double_as_longlong(axd);
+#else
+    __builtin_memcpy(&hb, &axd, sizeof hb);
+#endif
+    hb = (hb & 0xFFFFFFFF00000000ULL) - 0x0020000000000000ULL;
+    double qx;
+#if defined(__HIP_DEVICE_COMPILE__)
+    qx = __longlong_as_double((long long)hb);
+#else
+    __builtin_memcpy(&qx, &hb, sizeof qx);
+#endif
+    qx = ax > 0.78125 ? 0.28125 : qx;
+    qx = ax < 0.3 ? 0.0 : qx;
+    const double hz = 0.5 * z - qx, a = 1.0 - qx;
+    const double c = a - (hz - (z * rc - y0 * y1));                     // __kernel_cos(y0, y1)
+    const int n = (int)fn & 3;
+    *sn = n == 0 ? s : (n == 1 ? c : (n == 2 ? -s : -c));
+    *cs = n == 0 ? c : (n == 1 ? -s : (n == 2 ? -c : s));
 }
 
 // f64::is_normal() && is_sign_positive()  (raytracing/scene.rs:249)

@@ -67,3 +67,17 @@ def fuzz_scene(rtx, rng):
         d = np.eye(3)[int(rng.integers(0, 3))] * float(rng.choice([-1.0, 1.0]))     # axis-parallel view
     cam = (tuple(pos), tuple(d), float(rng.uniform(0.3, 2.5)))
     return o, cam
+
+
+def sincos_args():
+    """random_direction's angles: theta = u * 2 * pi for u in [0, 1) (vector.rs:38), plus the places a range reduction goes wrong:
+    both ends, every multiple of pi / 4 and its neighbours (the quadrant boundaries; next to k * pi / 2 the reduced argument is the
+    rounding error of pi itself), and tiny angles."""
+    rng = np.random.default_rng(11)
+    u = np.concatenate([rng.random(1 << 20), rng.integers(0, 1 << 53, 1 << 12) / 2.0 ** 53, [0.0, 2.0 ** -53, 1.0 - 2.0 ** -53, 0.5, 0.25, 0.125]])
+    th = u * 2.0 * math.pi
+    edges = np.arange(0, 9) * (math.pi / 4)
+    edges = np.concatenate([edges, np.nextafter(edges, 10.0), np.nextafter(edges, -10.0)])
+    near = np.concatenate([np.arange(0, 9) * (math.pi / 4) + d for d in (0.0, 1e-17, -1e-17, 1e-12, -1e-12, 1e-7, -1e-7, 3e-4, -3e-4)])
+    near = near[(near >= 0) & (near <= 2 * math.pi)]
+    return np.concatenate([th, edges[(edges >= 0) & (edges <= 2 * math.pi)], near, 10.0 ** rng.uniform(-300, 0, 4096)])

@@ -3,10 +3,14 @@
 Tolerance (stated once, used everywhere): the arithmetic is f64 in the reference's operation order, / and
 sqrt are correctly rounded on gfx950 (test_device_div_sqrt_are_correctly_rounded), and the column/row
 sin/cos of get_ray_dir come from host libm, so the only divergence from the oracle is the device's
-sin/cos in random_direction (vector.rs:38-42), which differ from glibc's by <= 1 ulp on ~3 % of arguments.
-A 1-ulp difference moves a pixel by ~1e-15 unless it flips a discrete hit/miss decision.
+sin/cos in random_direction (vector.rs:38-42; rtx_math.h sincos_2pi), which differ from glibc's by <= 1 ulp on
+~15 % of arguments -- as two libms do.  A 1-ulp difference moves a pixel by ~1e-15 unless it flips a discrete hit/miss decision.
     ATOL = 1e-9 absolute per channel, on every pixel (no outlier allowance needed in these cases).
 Integer outputs (segment counts, u8 images, camera matrices, RNG) are compared bit-exactly.
+That the sin / cos IS the only divergence is itself tested: the oracle can be switched to the device's routine
+(oracle.device_sincos(): the same operations on the CPU), and then every image must equal the oracle's BIT FOR BIT
+(test_hip_equals_the_oracle_bit_for_bit_with_the_device_sincos) -- also on the axis-aligned meshes where a last-place
+difference in a bounce direction flips a path.
 """
 import json
 import math
@@ -16,7 +20,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import DEFAULT_CAM, fuzz_scene, hip_render, hip_scene, max_abs_diff, oracle_render
+from helpers import DEFAULT_CAM, fuzz_scene, hip_render, hip_scene, max_abs_diff, oracle_render, sincos_args
 
 pytestmark = pytest.mark.gpu
 ATOL = 1e-9
@@ -49,7 +53,16 @@ def test_device_div_sqrt_are_correctly_rounded(gpu):
     assert np.array_equal(gpu.debug_math(1, a), np.sqrt(a))
 
 
-def test_device_sin_cos_within_one_ulp_of_libm(gpu):
+def test_device_sin_cos_within_one_ulp_of_libm(gpu, oracle):
+    """Ops 9 / 10: the sin / cos the path uses for random_direction's angle (rtx_math.h sincos_2pi) over that angle's range and
+    the hard places of a range reduction -- within one ulp of this libm's, and bit for bit what the oracle's restatement of the
+    routine gives on the CPU.  Ops 2 / 3 (the device library's general sin / cos, not on the path) for comparison."""
+    th = sincos_args()
+    s, c = oracle.device_sincos_values(th)
+    for op, ref, same in ((9, np.sin(th), s), (10, np.cos(th), c)):
+        got = gpu.debug_math(op, th)
+        assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref)))
+        assert np.array_equal(got, same)
     th = np.random.default_rng(1).uniform(0, 2 * math.pi, 1 << 18)
     for op, ref in ((2, np.sin(th)), (3, np.cos(th))):
         got = gpu.debug_math(op, th)
@@ -121,6 +134,87 @@ def test_hip_matches_oracle_seeded(gpu, oracle, case):
         img = scene.render(w, h)
         assert max_abs_diff(img, ref) <= ATOL, (case, kern)
         assert np.isfinite(img).all()
+
+
+def test_hip_equals_the_oracle_bit_for_bit_with_the_device_sincos(gpu, oracle):
+    """The stated tolerance has ONE source: random_direction's sin / cos (libm on the CPU, sincos_2pi on the device).  With the
+    oracle switched to the device's routine (the same operations, on the CPU) nothing is left to differ, and every image and
+    segment count must be EQUAL: the golden scenes, the seeded scenes, 60 fuzz scenes, and the axis-aligned mesh with bouncing
+    materials -- the case where the libm oracle and the kernels part on a handful of pixels (a hit point on a face x = const lands
+    on the face or one ulp off; a last-place difference in a bounce direction flips that for a later hit)."""
+    import torch
+    from rust_raytracing_amd import scenes
+    kerns = (gpu.RTX_KERNEL_EXACT, gpu.RTX_KERNEL_AUTO, gpu.RTX_KERNEL_BVH, gpu.RTX_KERNEL_WAVEFRONT)
+    cases = []
+    for name in ("c1_three_spheres_32x32", "spheres200_48x27", "mixed_40x24", "tris300_32x18"):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        cases.append((name, np.frombuffer(z["objects"].tobytes(), dtype=gpu.OBJECT_DTYPE), int(z["width"]), int(z["height"]), DEFAULT_CAM,
+                      json.loads(str(z["config"]))))
+    cases += [("c1", scenes.three_spheres(), 256, 256, DEFAULT_CAM, dict(rays_per_pixel=1, seed=42)),
+              ("spheres2k", scenes.compact(scenes.random_spheres(2000, 1), k=0.3), 96, 54, DEFAULT_CAM, dict(rays_per_pixel=4, seed=42)),
+              ("mixed", scenes.mixed_scene(60, 50, 2, seed=21), 64, 40, DEFAULT_CAM, dict(rays_per_pixel=4, seed=3)),
+              ("tris20k", scenes.random_triangles(20000, 6, box=0.3), 64, 36, DEFAULT_CAM, dict(rays_per_pixel=2, seed=4)),
+              ("c2 recipe", scenes.random_spheres(10000, 1), 160, 90, scenes.CAMERA, dict(rays_per_pixel=4, seed=42))]
+    mesh = scenes.axis_aligned_mesh()
+    for cam in (scenes.CAMERA, ((11.0, 0.2, 0.1), (0.3, 1.0, 0.2), 1.4), ((11.0, 0.0, 6.0), (0.0, 0.0, -1.0), 1.2)):
+        cases.append(("axis-aligned mesh", mesh, 96, 54, cam, dict(rays_per_pixel=2, seed=42)))
+    rng = np.random.default_rng(77)
+    for it in range(60):
+        objs, cam = fuzz_scene(gpu, rng)
+        cases.append(("fuzz %d" % it, objs, 20, 12, cam, dict(rays_per_pixel=2, seed=it, max_bounces=int(rng.choice([3, 10])))))
+    differ = 0
+    for name, objs, w, h, cam, cfg in cases:
+        libm = oracle_render(oracle, objs, w, h, cam=cam, **cfg)
+        with oracle.device_sincos():
+            ref, seg = oracle_render(oracle, objs, w, h, cam=cam, want_segments=True, **cfg)
+        differ += not np.array_equal(libm, ref, equal_nan=True)
+        for kern in kerns:
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, **cfg).upload(0)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            hnd.close()
+            assert np.array_equal(buf.cpu().numpy(), ref, equal_nan=True), (name, kern)
+            assert st.segments == int(seg.sum()), (name, kern)
+    assert differ >= 2                     # (images are functions of hit sequences: a last-place change shows in few of them -- but
+                                           #  it does: the two forms of the oracle are not the same function, the switch was live)
+
+
+def test_path_transcripts_equal_the_oracles(gpu, oracle):
+    """An image compares hit SEQUENCES (a colour is a product of materials and a light); a transcript compares the arithmetic: per
+    segment the ray closest_object was asked about, the winning distance, the winner (rtx_debug_paths of the lab library -- the
+    exhaustive f64 kernel's loop, writing down -- against rtxo_trace_row).  Every path of every row of four scenes (spheres; spheres,
+    planes and triangles; a random mesh; the axis-aligned mesh):
+      * against the libm oracle the PRIMARY ray (step 0: scene.rs:194-207, the host's trig tables, the lens draws) and its hit are
+        equal to the last bit -- this caught glibc's sincos() differing from its sin() / cos() when one side's compiler had merged
+        the pair and the other's had not;
+      * against the oracle on the device's sin / cos routine EVERY step is equal to the last bit: positions, bounce directions,
+        distances, objects, lengths."""
+    from rust_raytracing_amd import scenes
+    cases = [("c2 recipe", scenes.random_spheres(10000, 1), 160, 90, scenes.CAMERA, dict(rays_per_pixel=4, seed=42)),
+             ("mixed", scenes.mixed_scene(60, 50, 2, seed=21), 64, 40, DEFAULT_CAM, dict(rays_per_pixel=4, seed=3)),
+             ("tris", scenes.light_every(scenes.compact(scenes.random_triangles(400, 5)), 3), 48, 32, DEFAULT_CAM, dict(rays_per_pixel=3, seed=8)),
+             ("axis-aligned mesh", scenes.axis_aligned_mesh(), 96, 54, ((11.0, 0.2, 0.1), (0.3, 1.0, 0.2), 1.4), dict(rays_per_pixel=2, seed=42))]
+    max_steps, bounced = 12, 0
+    for name, objs, w, h, cam, cfg in cases:
+        sc = oracle.make_scene(objs, cam, **cfg)
+        hnd = hip_scene(gpu, objs, cam=cam, kernel=gpu.RTX_KERNEL_EXACT, **cfg).upload(0, lab=True)
+        for row in range(h):
+            steps, counts = hnd.debug_paths(w, h, row, max_steps)
+            libm_steps, _ = oracle.trace_row(sc, w, h, row, max_steps)
+            assert steps[:, :, 0].tobytes() == libm_steps[:, :, 0].tobytes(), (name, row)
+            with oracle.device_sincos():
+                want, want_counts = oracle.trace_row(sc, w, h, row, max_steps)
+            assert np.array_equal(counts, want_counts), (name, row)
+            assert steps.tobytes() == want.tobytes(), (name, row)
+            bounced += int((counts > 1).sum())
+        hnd.close()
+    assert bounced > 5000
+    # the product library has no such hook
+    hnd = hip_scene(gpu, scenes.three_spheres(), kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=1).upload(0)
+    with pytest.raises(gpu.RtxError) as e:
+        hnd.debug_paths(8, 8, 0, 4)
+    assert e.value.status == gpu.abi.RTX_ERR_UNSUPPORTED
+    hnd.close()
 
 
 def test_mixed_kernel_is_bit_identical_to_exact_kernel(gpu):
