@@ -365,7 +365,8 @@ static inline rtxo_vec3 ctx_normal_at(const render_ctx *c, uint64_t i, rtxo_vec3
 /* ------------------------------------------------------------------------------------------- */
 /* sin / cos of random_direction's angle.  Mode 0 (the default, and what the reference does): the platform libm, f64::cos / f64::sin
  * (vector.rs:40-41).  Mode 1 -- a test mode, not the reference: the routine the DEVICE uses for this angle (the product's
- * rtx_math.h sincos_2pi, restated here operation for operation: fdlibm's medium-argument reduction and __kernel_sin / __kernel_cos).
+ * rtx_math.h sincos_2pi, restated here operation for operation: an exact reduction by pi/2, fdlibm's polynomials on [-pi/4, pi/4]
+ * with the squares' rounding errors carried along, one final rounding).
  * No two libms agree on the last bit of sin / cos, so that is the one place the device may differ from this oracle (<= 1 ulp, images
  * within 1e-9); with mode 1 the difference is gone and the kernels must equal the oracle BIT FOR BIT, which turns every seeded
  * comparison of the test suite into an exact one (tests/test_gpu_parity.py). */
@@ -375,31 +376,29 @@ void rtxo_set_sincos_mode(int mode) { g_sincos_mode = mode; }
 void rtxo_device_sincos(double x, double *sn, double *cs)
 {
     static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
-                        pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21,
-                        pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;
+                        pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
     static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                         S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                         C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double fn = rint(x * invpio2);
-    double r = x - fn * pio2_1, w, t;
-    t = r; w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
-    t = r; w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
-    const double y0 = r - w, y1 = (r - y0) - w;
-    const double z = y0 * y0, v = z * y0;
+    const double fn = rint(x * invpio2);                              /* n = 0..4 for x in [0, 2 pi] */
+    const double r1 = x - fn * pio2_1, w2 = fn * pio2_2;              /* x - n pi/2: exact, exact, */
+    const double r = r1 - w2;                                         /* rounded -- the error joins the third piece */
+    const double w = fn * pio2_2t - ((r1 - r) - w2);
+    const double y0 = r - w, y1 = (r - y0) - w;                       /* the reduced angle and its tail */
+    const double z = y0 * y0, zl = fma(y0, y0, -z);
+    const double v = z * y0, vl = fma(z, y0, -v) + zl * y0;
     const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    double sm = z * (v * rs - 0.5 * y1) + y1;
+    sm = fma(vl, S1, sm);
+    sm = fma(v, S1, sm);
+    const double s = y0 + sm;
     const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    const double ax = fabs(y0);
-    uint64_t hb;
-    memcpy(&hb, &ax, sizeof hb);
-    hb = (hb & 0xFFFFFFFF00000000ULL) - 0x0020000000000000ULL;
-    double qx;
-    memcpy(&qx, &hb, sizeof qx);
-    qx = ax > 0.78125 ? 0.28125 : qx;
-    qx = ax < 0.3 ? 0.0 : qx;
-    const double hz = 0.5 * z - qx, a = 1.0 - qx;
-    const double c = a - (hz - (z * rc - y0 * y1));
+    const double h = 0.5 * z, w1 = 1.0 - h;
+    double cm = fma(z, rc, -(y0 * y1));
+    cm = fma(-0.5, zl, cm);
+    cm = ((1.0 - w1) - h) + cm;
+    const double c = w1 + cm;
     const int n = (int)fn & 3;
     *sn = n == 0 ? s : (n == 1 ? c : (n == 2 ? -s : -c));
     *cs = n == 0 ? c : (n == 1 ? -s : (n == 2 ? -c : s));

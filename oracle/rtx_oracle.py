@@ -55,9 +55,9 @@ class Scene(C.Structure):
 def build(force=False):
     """Compile oracle/librtx_oracle.so with gcc (recipe: oracle/Makefile)."""
     src = os.path.join(_HERE, "rtx_oracle.c")
-    hdr = os.path.join(_HERE, "rtx_oracle.h")
+    hdrs = [os.path.join(_HERE, "rtx_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in [src] + hdrs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "librtx_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -82,52 +82,48 @@ RTX_HD double rng_u01(uint64_t key, uint32_t draw_index)              // fastran
 }
 
 // sin and cos of an angle in [0, 2 pi] -- Vector3::random_direction's theta = u * 2 * pi (vector.rs:38-42), the path's only
-// transcendental call.  The reference calls the platform libm; no two libms agree on the last bit of sin / cos, so this is where the
-// device was always allowed to differ (tests: <= 1 ulp from glibc; images within 1e-9).  The device library's sincos() is a general
-// routine (Payne-Hanek reduction for any argument: ~175 instructions in a phase that is issue-bound); for this range fdlibm's
-// medium-argument path does: n = rint(x * 2/pi) in 0..4, x - n * pi/2 in three exact-product steps (33 + 33 + 53 bits of pi/2:
-// a 118-bit pi/2, so arguments next to a multiple of pi/2 keep their relative accuracy), then fdlibm's __kernel_sin / __kernel_cos
-// polynomials on [-pi/4, pi/4] with the reduction's tail (each < 1 ulp), and the quadrant's swap / signs.  77 instructions.
-// Plain mul / add in fdlibm's order (no contraction), so the same operations on a CPU give the same bits: the test suite's CPU
-// checker has a mode that restates this routine, and then the kernels must equal it bit for bit (tests/test_gpu_parity.py).
+// transcendental call.  The reference calls the platform libm; no two libms agree on the last bit of sin / cos everywhere, so this is
+// the one place the device may differ from a CPU run (tests: <= 1 ulp from glibc; images within 1e-9 unless a path flips).  The device
+// library's sincos() is a general routine (any argument: ~175 instructions and enough registers to push the sphere kernels' ray state
+// into scratch -- 33-59 spilled registers, 4-6 without it) that differs from glibc's on ~3 % of arguments.  For this range:
+//     n = rint(x * 2/pi) in 0..4;  y = x - n * pi/2 with pi/2 in three pieces (33 + 33 + 53 bits): the first product and difference
+//     are exact, the second difference's rounding error is recovered (Fast2Sum) and joins the third piece in the tail: y0 + y1;
+//     fdlibm's polynomials for sin and cos on [-pi/4, pi/4] (S1..S6, C1..C6), evaluated so that the result is ONE rounding of
+//     leading term + everything small: the squares' and cube's rounding errors (fma tails: zl, vl) are carried in the small sums,
+//     which brings the worst error found from fdlibm's ~0.8 ulp to 0.58 (against 200-bit values);  the quadrant swaps / negates.
+// Differs from glibc's sincos() on 1.4 % of arguments (never by more than one ulp).  ~80 instructions, no memory, few registers.
+// Explicit fma() / mul / add in a fixed order, nothing left to contraction: the same operations on a CPU give the same bits -- the
+// test suite's CPU checker has a mode that restates this routine, and then the kernels must equal it bit for bit
+// (tests/test_gpu_parity.py).  (A 33-row table of sin / cos(n pi/16) with Taylor remainders was 0.23 % and fewer instructions, but
+// its eight table values stayed live beside the ray state: the spills came back and with them the time -- LAB_NOTEBOOK R4.9.)
 RTX_HD void sincos_2pi(double x, double *sn, double *cs)
 {
     const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
-                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21,
-                 pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;
+                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double fn = rint(x * invpio2);
-    double r = x - fn * pio2_1, w, t;                                   // (fn * pio2_1 is exact: 3 x 33 bits)
-    t = r; w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
-    t = r; w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
-    const double y0 = r - w, y1 = (r - y0) - w;                         // the reduced argument and its tail
-    const double z = y0 * y0, v = z * y0;
+    const double r1 = x - fn * pio2_1, w2 = fn * pio2_2;              // both exact (33-bit pieces, n <= 4; Sterbenz)
+    const double r = r1 - w2;
+    const double w = fn * pio2_2t - ((r1 - r) - w2);                  // the third piece minus what the difference above dropped
+    const double y0 = r - w, y1 = (r - y0) - w;                       // the reduced angle and its tail, |y| <= pi/4
+    const double z = y0 * y0, zl = fma(y0, y0, -z);                   // y0^2 = z + zl
+    const double v = z * y0, vl = fma(z, y0, -v) + zl * y0;           // y0^3 = v + vl
+    // sin y = y0 + [ y1 + (v + vl) S1 + v z (S2 + ...) - z y1 / 2 ]
     const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);    // __kernel_sin(y0, y1, 1)
+    double sm = z * (v * rs - 0.5 * y1) + y1;
+    sm = fma(vl, S1, sm);
+    sm = fma(v, S1, sm);
+    const double s = y0 + sm;
+    // cos y = (1 - z/2) + [ rounding of that difference - zl/2 + z (z (C1 + ...)) - y0 y1 ]
     const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    const double ax = fabs(y0);
-    // __kernel_cos's qx: 0 below 0.3, |x| / 4 with the low word cleared up to 0.78125, 0.28125 above
-    double axd = ax;
-    uint64_t hb;
-#if defined(__HIP_DEVICE_COMPILE__)
-    hb = (uint64_t)__double_as_longlong(axd);
-#else
-    __builtin_memcpy(&hb, &axd, sizeof hb);
-#endif
-    hb = (hb & 0xFFFFFFFF00000000ULL) - 0x0020000000000000ULL;
-    double qx;
-#if defined(__HIP_DEVICE_COMPILE__)
-    qx = __longlong_as_double((long long)hb);
-#else
-    __builtin_memcpy(&qx, &hb, sizeof qx);
-#endif
-    qx = ax > 0.78125 ? 0.28125 : qx;
-    qx = ax < 0.3 ? 0.0 : qx;
-    const double hz = 0.5 * z - qx, a = 1.0 - qx;
-    const double c = a - (hz - (z * rc - y0 * y1));                     // __kernel_cos(y0, y1)
+    const double h = 0.5 * z, w1 = 1.0 - h;
+    double cm = fma(z, rc, -(y0 * y1));
+    cm = fma(-0.5, zl, cm);
+    cm = ((1.0 - w1) - h) + cm;
+    const double c = w1 + cm;
     const int n = (int)fn & 3;
     *sn = n == 0 ? s : (n == 1 ? c : (n == 2 ? -s : -c));
     *cs = n == 0 ? c : (n == 1 ? -s : (n == 2 ? -c : s));

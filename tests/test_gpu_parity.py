@@ -35,6 +35,16 @@ def gpu(rtx):
     return rtx
 
 
+def two_sided(oracle, img, objs, w, h, cam=DEFAULT_CAM, flips=1, **cfg):
+    """The tolerance statement where a path DOES flip on the last bit of a sin / cos: equal, bit for bit, to the oracle that uses the
+    device's routine; within ATOL of the libm oracle on all but `flips` pixels (whose paths took another turn)."""
+    with oracle.device_sincos():
+        assert np.array_equal(img, oracle_render(oracle, objs, w, h, cam=cam, **cfg), equal_nan=True)
+    off = int((np.abs(img - oracle_render(oracle, objs, w, h, cam=cam, **cfg)).max(axis=2) > ATOL).sum())
+    assert off <= flips, off
+    return off
+
+
 def _kernels(rtx):
     """Every kernel id through the product library (librtx_hip.so: one tree-kernel family per kind of tree, whichever tree id is
     asked for) and the three tree ids through the lab library (librtx_hip_lab.so: one family per id -- round 1's lock-step and
@@ -610,7 +620,7 @@ def test_mesh_kernel_paths(gpu, oracle):
     co["emission_color"][100:114] = np.linspace(0.1, 0.9, 14)[:, None]
     co["base_color"][100:114] = 0.0
     img, segs, exact = both(co, scenes.CAMERA)
-    assert max_abs_diff(img, oracle_render(oracle, co, 64, 36, rays_per_pixel=2, seed=42)) <= ATOL
+    two_sided(oracle, img, co, 64, 36, cam=scenes.CAMERA, rays_per_pixel=2, seed=42)    # (one path of this frame turns on a last bit)
     assert exact < 40 * segs and img.mean() > 0.01                            # flushes, not the exhaustive fallback (4000 per segment)
     for cam in (((-300.0, 2.0, 1.0), (1.0, 0.0, 0.0), 0.05),                  # outside origin_limit: the f64 slab walk
                 ((-3.0e12, 0.0, 0.0), (1.0, 0.0, 0.0), 1e-11),                # beyond it: every shape, exactly
