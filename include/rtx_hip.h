@@ -145,6 +145,9 @@ enum {
     RTX_TUNE_STAGE2_SLOTS = 1u << 26, /* sphere trees, two stages: stage 2 over ray slots (trace_sph_slots_kernel: a wave owns ~90 rays, a lane
                                         whose walk ends takes the next READY one from LDS, the f64 phase runs for 64 finished walks at once;
                                         round 4's experiment: 12 % fewer instructions, the same time -- LAB_NOTEBOOK R4.3) */
+    RTX_TUNE_HALVES = 1u << 27,      /* sphere trees, two stages: the launch as two halves of the samples in flight on two streams (one
+                                      * drain instead of four) whatever its size; default: launches of <= 2^26 rays */
+    RTX_TUNE_NO_HALVES = 1u << 28,   /* ... never */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };
@@ -153,7 +156,8 @@ enum {
                            RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR | RTX_TUNE_BEAMS | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_SORT_SURVIVORS | \
                            RTX_TUNE_STAGE2_SLOTS)
 #define RTX_TUNE_KNOWN_MASK (RTX_TUNE_LAB_MASK | RTX_TUNE_NO_TILES | RTX_TUNE_ONE_STAGE | RTX_TUNE_TWO_STAGE | RTX_TUNE_BVH_MEDIAN | \
-                             (15u << RTX_TUNE_TRI_LEAF_SHIFT) | (127u << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT)
+                             (15u << RTX_TUNE_TRI_LEAF_SHIFT) | (127u << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT | RTX_TUNE_HALVES | \
+                             RTX_TUNE_NO_HALVES)
 
 /* Camera (camera.rs:7-15).  to_world_space / to_cam_space are the three ROWS of each matrix
  * (mat.rs:11-18), row-major.  Only fov, position and to_world_space are read by render

@@ -75,6 +75,14 @@ bool debug_prints()
 
 }  // namespace
 
+#ifndef RTX_GRABS_PER_WAVE
+#define RTX_GRABS_PER_WAVE 16          // (render_band: grabs a wave makes from the ray queue)
+#endif
+
+// A two-stage sphere launch of at most this many rays runs as two halves in flight (render_band); above it the drain is < 2 % and
+// the halves' second set of queue and stack columns is not worth holding.  Measured: LAB_NOTEBOOK R4.10.
+constexpr uint64_t kHalvesBelowRays = 1ull << 26;
+
 struct RtxSceneHandle_ {
     int device = 0;
     int n_cus = 0;
@@ -98,6 +106,16 @@ struct RtxSceneHandle_ {
     SceneView *d_sv = nullptr;  bool sv_dirty = true;     // device copy of sv (kernels take it by pointer)
     RowsView *d_rv = nullptr;
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };      // [3]: the end of the sphere kernel's stage 1 (stats only)
+    // The second half's own stream and buffers when a launch runs as two halves in flight (render_band, "halves"): created on first use.
+    struct SecondHalf {
+        hipStream_t stream = nullptr;
+        hipEvent_t fork = nullptr, join = nullptr, stage1_done = nullptr;
+        Counters *counters = nullptr, *counters_stage1 = nullptr;
+        unsigned long long *work_counter = nullptr;
+        RowsView *d_rv = nullptr;
+        double *state = nullptr;    size_t state_bytes = 0;
+        void *queue = nullptr;      size_t queue_bytes = 0;
+    } half2;
     Counters *counters_stage1 = nullptr;                   // the counters as stage 1 left them (stats only)
     // The handle's device buffers (descriptors, tables, counters, scratch) are shared by all of its renders, so they
     // are ordered on ONE stream at a time: when a call brings a different stream the previous one is drained first.
@@ -194,6 +212,13 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->work_counter) (void)hipFree(h->work_counter);
     if (h->d_sv) (void)hipFree(h->d_sv);
     if (h->d_rv) (void)hipFree(h->d_rv);
+    {
+        auto &b = h->half2;
+        if (b.stream) { (void)hipStreamSynchronize(b.stream); (void)hipStreamDestroy(b.stream); }
+        for (hipEvent_t e : { b.fork, b.join, b.stage1_done }) if (e) (void)hipEventDestroy(e);
+        for (void *q : { (void *)b.counters, (void *)b.counters_stage1, (void *)b.work_counter, (void *)b.d_rv, (void *)b.state, b.queue })
+            if (q) (void)hipFree(q);
+    }
     if (h->h_watchdog) (void)hipHostFree(h->h_watchdog);
     if (h->ev_watchdog) (void)hipEventDestroy(h->ev_watchdog);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -528,8 +553,8 @@ int32_t create_handle(const RtxScene *scene, const PackedScene &p, int32_t devic
     if (e == hipSuccess) e = hipMalloc((void **)&h->work_counter, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_sv, sizeof(SceneView));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_rv, sizeof(RowsView));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_watchdog, sizeof(unsigned long long), hipHostMallocDefault);
-    if (e == hipSuccess) { *h->h_watchdog = 0ull; e = hipEventCreateWithFlags(&h->ev_watchdog, hipEventDisableTiming); }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_watchdog, 2 * sizeof(unsigned long long), hipHostMallocDefault);   // [1]: the second half's
+    if (e == hipSuccess) { h->h_watchdog[0] = h->h_watchdog[1] = 0ull; e = hipEventCreateWithFlags(&h->ev_watchdog, hipEventDisableTiming); }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
     for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&h->ev[k]);
     if (e != hipSuccess) { free_handle(h); return fail(RTX_ERR_HIP, std::string("scene scratch: ") + hipGetErrorString(e)); }
@@ -548,9 +573,9 @@ int32_t check_watchdog(RtxSceneHandle_ *h, bool wait)
         RTX_HIP_CHECK(q);
     }
     h->watchdog_pending = false;
-    if (*h->h_watchdog != 0ull) {
-        const unsigned long long n = *h->h_watchdog;
-        *h->h_watchdog = 0ull;
+    if ((h->h_watchdog[0] | h->h_watchdog[1]) != 0ull) {
+        const unsigned long long n = h->h_watchdog[0] + h->h_watchdog[1];
+        h->h_watchdog[0] = h->h_watchdog[1] = 0ull;
         return fail(RTX_ERR_HIP, "an earlier render on this scene raised its watchdog word (internal error: the sweep kernel's round "
                                  "bound, or a full survivors' queue): " + std::to_string(n) + " event(s); its image is incomplete");
     }
@@ -939,7 +964,97 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         rv.n_samples = 0; rv.n_rays = 0; rv.tiles_x = 0;
         RTX_HIP_CHECK(launch_resolve(nullptr, nullptr, d_out_rgb, rv, npix, 0, true, true, stream));
     }
-    for (uint64_t s0 = 0; s0 < spp; s0 += batch) {
+    // ---- two halves in flight (sphere trees, two stages).  A persistent launch ends with a drain -- the last rays of the last waves
+    // have up to ten dependent rounds to go while the rest of the chip is idle, ~0.7 ms per stage whatever the launch's size: 2 % of a
+    // C2 frame, 12 % of the band one of 8 GPUs renders.  Sample batches are independent (the left fold happens in resolve), so the
+    // launch is cut into two halves of the samples with their own queues, counters and stack columns, on two streams: each stage's
+    // grid fills the chip, so a later kernel's workgroups become resident exactly as an earlier one's leave -- stage 1 of half B runs
+    // in the drain of half A's, stage 2 of A in the drain of B's stage 1, ... and one drain is left at the end instead of four.  The
+    // samples of both halves lie where one launch would have put them: ONE resolve, the same bits (tests).  A launch counts once
+    // (RtxStats.trace_launches), trace_ms is the whole region's time, stage1_ms the time until both halves' primary rays were done.
+    const uint32_t sph_flags = ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u) |
+                               ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u) | ((tuning & RTX_TUNE_STAGE2_PAIR) ? 8u : 0u);   // (lab forms of the sphere kernel)
+#ifdef RTX_LAB
+    const bool halves_can = spheres_two_stage && batch == spp && spp >= 2 && !stage2_slots &&
+                            (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) == 0u;
+#else
+    const bool halves_can = spheres_two_stage && batch == spp && spp >= 2;
+#endif
+    const bool halves = halves_can && (tuning & RTX_TUNE_NO_HALVES) == 0u &&
+                        ((tuning & RTX_TUNE_HALVES) != 0u || per_sample64 * spp <= kHalvesBelowRays);
+    if (halves) {
+        auto &b = h->half2;
+        if (!b.stream) {
+            RTX_HIP_CHECK(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+            RTX_HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
+            RTX_HIP_CHECK(hipEventCreateWithFlags(&b.join, hipEventDisableTiming));
+            RTX_HIP_CHECK(hipEventCreate(&b.stage1_done));
+            RTX_HIP_CHECK(hipMalloc((void **)&b.counters, sizeof(Counters) * kCounterShards));
+            RTX_HIP_CHECK(hipMalloc((void **)&b.counters_stage1, sizeof(Counters) * kCounterShards));
+            RTX_HIP_CHECK(hipMalloc((void **)&b.work_counter, sizeof(unsigned long long)));
+            RTX_HIP_CHECK(hipMalloc((void **)&b.d_rv, sizeof(RowsView)));
+        }
+        const uint64_t ns[2] = { (spp + 1) / 2, spp / 2 };
+        if (int32_t rc = grow((void **)&b.state, &b.state_bytes, bvh_spheres_spill_bytes(h->sv, h->n_cus))) return rc;
+        if (int32_t rc = grow(&b.queue, &b.queue_bytes, bvh_spheres_queue_bytes(ns[1] * per_sample64, h->n_cus))) return rc;
+        // whatever way this block is left, the caller's stream waits for the second one (the handle's buffers are ordered on ONE stream)
+        struct Join {
+            RtxSceneHandle_ *h; hipStream_t main; bool forked = false;
+            ~Join() {
+                if (!forked) return;
+                if (hipEventRecord(h->half2.join, h->half2.stream) != hipSuccess || hipStreamWaitEvent(main, h->half2.join, 0) != hipSuccess) {
+                    (void)hipGetLastError(); (void)hipStreamSynchronize(h->half2.stream);
+                }
+            }
+        } join{h, stream};
+        RTX_HIP_CHECK(hipMemsetAsync(b.counters, 0, sizeof(Counters) * kCounterShards, stream));
+        if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[0], stream));
+        RTX_HIP_CHECK(hipEventRecord(b.fork, stream));                 // (behind the tables, the scene descriptor and the zeroed counters)
+        RTX_HIP_CHECK(hipStreamWaitEvent(b.stream, b.fork, 0));
+        join.forked = true;
+        RowsView rvk[2] = { rv, rv };
+        for (int k = 0; k < 2; ++k) {
+            RowsView &r = rvk[k];
+            r.sample_begin = k == 0 ? 0u : (uint32_t)ns[0];
+            r.n_samples = (uint32_t)ns[k];
+            r.n_rays = per_sample64 * ns[k];
+            r.tiles_x = tiles_x;
+            const uint64_t per_wave = r.n_rays / ((uint64_t)h->n_cus * 16u * RTX_GRABS_PER_WAVE);
+            r.grab = (uint32_t)(per_wave >= 512 ? 512 : (per_wave <= 64 ? 64 : (per_wave & ~(uint64_t)63)));
+            hipStream_t st = k == 0 ? stream : b.stream;
+            RTX_HIP_CHECK(hipMemcpyAsync(k == 0 ? h->d_rv : b.d_rv, &r, sizeof(RowsView), hipMemcpyHostToDevice, st));   // pageable: staged before return
+            RTX_HIP_CHECK(hipMemsetAsync(k == 0 ? h->work_counter : b.work_counter, 0, sizeof(unsigned long long), st));
+            RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, k == 0 ? h->d_rv : b.d_rv, r,
+                                                   h->samples + (k == 0 ? 0 : (size_t)(per_sample64 * ns[0]) * 4), k == 0 ? h->counters : b.counters,
+                                                   k == 0 ? h->work_counter : b.work_counter, reinterpret_cast<uint32_t *>(k == 0 ? h->state : b.state),
+                                                   h->n_cus, k == 0 ? h->wf_state : b.queue, sph_flags, st,
+                                                   stats ? (k == 0 ? h->counters_stage1 : b.counters_stage1) : nullptr,
+                                                   stats ? (k == 0 ? h->ev[3] : b.stage1_done) : nullptr, nullptr, nullptr));
+        }
+        RTX_HIP_CHECK(hipEventRecord(b.join, b.stream));
+        RTX_HIP_CHECK(hipStreamWaitEvent(stream, b.join, 0));
+        join.forked = false;                                            // joined
+        launches = 1;
+        if (stats) RTX_HIP_CHECK(hipEventRecord(h->ev[1], stream));
+        rv.sample_begin = 0; rv.n_samples = (uint32_t)spp; rv.n_rays = per_sample64 * spp; rv.tiles_x = tiles_x;
+        RTX_HIP_CHECK(launch_resolve(h->samples, h->acc, d_out_rgb, rv, per_sample, spp, true, true, stream));
+        if (stats) {
+            RTX_HIP_CHECK(hipEventRecord(h->ev[2], stream));
+            RTX_HIP_CHECK(hipEventSynchronize(h->ev[2]));
+            RTX_HIP_CHECK(hipEventElapsedTime(&trace_ms, h->ev[0], h->ev[1]));
+            RTX_HIP_CHECK(hipEventElapsedTime(&resolve_ms, h->ev[1], h->ev[2]));
+            float c0 = 0.f, c1 = 0.f;
+            RTX_HIP_CHECK(hipEventElapsedTime(&c0, h->ev[0], h->ev[3]));
+            RTX_HIP_CHECK(hipEventElapsedTime(&c1, h->ev[0], b.stage1_done));
+            stage1_ms = c0 > c1 ? c0 : c1;
+            for (Counters *snap : { h->counters_stage1, b.counters_stage1 }) {
+                Counters s1[kCounterShards];
+                RTX_HIP_CHECK(hipMemcpy(s1, snap, sizeof s1, hipMemcpyDeviceToHost));
+                for (int k = 0; k < kCounterShards; ++k) { s1_exact += s1[k].exact_tests; s1_filter += s1[k].filter_tests; if (k >= 2) s1_box += s1[k].pad_; }
+            }
+        }
+    }
+    for (uint64_t s0 = 0; s0 < spp && !halves; s0 += batch) {
         const uint64_t ns = (spp - s0 < batch) ? spp - s0 : batch;
         rv.sample_begin = (uint32_t)s0;
         rv.n_samples = (uint32_t)ns;
@@ -949,9 +1064,6 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
             // grabs per wave: what is left in a wave's last grab when the queue runs dry is the launch's tail.  Measured on the band
             // rank 0 of 8 owns of the C2 frame (1.67e7 rays, same box): 8: 7.33 ms, 16: 7.16, 32 and 64: 8.8 (a grab of 64 rays is one
             // atomic per tile: the one address retires ~80 M adds per second); the full frame does not care (50.4 / 50.3 / 50.2 / 50.4)
-#ifndef RTX_GRABS_PER_WAVE
-#define RTX_GRABS_PER_WAVE 16
-#endif
             const uint64_t per_wave = rv.n_rays / ((uint64_t)h->n_cus * 16u * RTX_GRABS_PER_WAVE);       // 16 resident waves per CU
             rv.grab = (uint32_t)(per_wave >= 512 ? 512 : (per_wave <= 64 ? 64 : (per_wave & ~(uint64_t)63)));
         }
@@ -995,9 +1107,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
                 RTX_HIP_CHECK(launch_trace_bvh_spheres(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->counters, h->work_counter,
                                                        reinterpret_cast<uint32_t *>(h->state), h->n_cus,
-                                                       spheres_two_stage ? h->wf_state : nullptr,
-                                                       ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u) |
-                                                           ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u) | ((tuning & RTX_TUNE_STAGE2_PAIR) ? 8u : 0u), stream,
+                                                       spheres_two_stage ? h->wf_state : nullptr, sph_flags, stream,
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
                                                        stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr,
                                                        stage2_slots ? h->slots : nullptr));
@@ -1042,6 +1152,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         if (h->watchdog_pending) RTX_HIP_CHECK(hipEventSynchronize(h->ev_watchdog));
         if (int32_t rc = check_watchdog(h, false)) return rc;
         RTX_HIP_CHECK(hipMemcpyAsync(h->h_watchdog, &h->counters[1].pad_, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        if (halves) RTX_HIP_CHECK(hipMemcpyAsync(h->h_watchdog + 1, &h->half2.counters[1].pad_, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         RTX_HIP_CHECK(hipEventRecord(h->ev_watchdog, stream));
         h->watchdog_pending = true;
     }
@@ -1050,6 +1161,14 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         RTX_HIP_CHECK(hipStreamSynchronize(stream));
         Counters host[kCounterShards];
         RTX_HIP_CHECK(hipMemcpy(host, h->counters, sizeof host, hipMemcpyDeviceToHost));
+        if (halves) {                                                  // the second half counted in its own shards
+            Counters more[kCounterShards];
+            RTX_HIP_CHECK(hipMemcpy(more, h->half2.counters, sizeof more, hipMemcpyDeviceToHost));
+            for (int k = 0; k < kCounterShards; ++k) {
+                host[k].segments += more[k].segments; host[k].exact_tests += more[k].exact_tests;
+                host[k].filter_tests += more[k].filter_tests; host[k].pad_ += more[k].pad_;
+            }
+        }
         for (int k = 0; k < kCounterShards; ++k) {
             stats->segments += host[k].segments;
             stats->exact_tests += host[k].exact_tests;
@@ -1058,7 +1177,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         stats->filter_mismatches = host[0].pad_;
         for (int k = 2; k < kCounterShards; ++k) stats->box_tests += host[k].pad_;
         if (host[1].pad_ != 0) {
-            h->watchdog_pending = false; *h->h_watchdog = 0ull;        // reported right here
+            h->watchdog_pending = false; h->h_watchdog[0] = h->h_watchdog[1] = 0ull;        // reported right here
             return fail(RTX_ERR_HIP, "trace kernel raised its watchdog word (internal error: round bound / full survivors' queue): " +
                                          std::to_string(host[1].pad_) + " event(s)");
         }

@@ -757,7 +757,9 @@ def test_ab_knobs_keep_the_bits(gpu):
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_POOL, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_SORT_SURVIVORS,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_PAIR | gpu.RTX_TUNE_NO_QNODES, gpu.RTX_TUNE_PK_LDS_STACK, gpu.RTX_TUNE_BEAMS, gpu.RTX_TUNE_BEAMS | gpu.RTX_TUNE_PK_LDS_STACK, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_CUT, gpu.RTX_TUNE_ONE_STAGE | gpu.RTX_TUNE_NO_CUT,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_INLINE_LEAVES | gpu.RTX_TUNE_NO_CUT,
-             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_SLOTS, gpu.RTX_TUNE_STAGE2_SLOTS]
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_SLOTS, gpu.RTX_TUNE_STAGE2_SLOTS,
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_HALVES, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_HALVES,
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_HALVES | gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_HALVES]
     # a knob with a RTX_TUNE_LAB_MASK bit renders through librtx_hip_lab.so (the product library refuses it, below); the others
     # through the product library and, as LabKernel ids, through the lab library's kernel family of each id
     L = gpu.LabKernel
@@ -784,6 +786,51 @@ def test_ab_knobs_keep_the_bits(gpu):
         assert rc == want, (bit, rc)
         if rc:
             assert b"tuning" in prod.rtx_last_error()
+    hnd.close()
+
+
+def test_two_halves_in_flight_keep_the_bits(gpu, oracle):
+    """A two-stage sphere launch of <= 2^26 rays runs as two halves of the samples on two streams with their own queues, counters
+    and stack columns (render_band: one drain instead of four).  Same image and counters as the single launch (RTX_TUNE_NO_HALVES)
+    and as the exhaustive kernel: even and odd sample counts, a band, a tree deep enough for the HBM stack columns, renders back to
+    back on one handle and on two caller streams; the statistics count it as ONE launch and add the halves' counters up."""
+    import torch
+    from rust_raytracing_amd import scenes
+    objs = scenes.random_spheres(10000, 1)
+    deep = scenes.random_spheres(3000, 2).copy()
+    deep["geom"][:, :3] *= np.logspace(0, 1.5, len(deep))[:, None]                 # sizes over 1.5 decades: a deeper tree
+    w, h = 512, 288
+    for name, o, spp in (("c2", objs, 8), ("c2", objs, 5), ("c2", objs, 2), ("deep", deep, 8)):
+        res = {}
+        for tag, tune in (("halves", gpu.RTX_TUNE_HALVES), ("one", gpu.RTX_TUNE_NO_HALVES), ("default", 0)):
+            hnd = hip_scene(gpu, o, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=spp, seed=42, tuning=tune).upload(0)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            again = torch.zeros_like(buf)
+            st2 = hnd.render_rows(w, h, 0, 1, h, again.data_ptr())                     # the second set is reused, not re-created
+            assert torch.equal(buf, again) and st2.segments == st.segments
+            res[tag] = (buf.cpu().numpy(), st)
+            hnd.close()
+        a, sa = res["halves"]
+        b, sb = res["one"]
+        assert sa.kernel == gpu.RTX_KERNEL_BVH and sa.trace_launches == 1 and sb.trace_launches == 1 and sa.stage1_ms > 0
+        assert np.array_equal(a, b) and np.array_equal(a, res["default"][0]), (name, spp)
+        for f in ("segments", "exact_tests", "filter_tests", "box_tests", "stage1_box_tests", "stage1_exact_tests", "primary_rays"):
+            assert getattr(sa, f) == getattr(sb, f), (name, spp, f)
+        if spp == 2:
+            ex = hip_render(gpu, o, w, h, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=spp, seed=42)
+            assert np.array_equal(a, ex)
+    # a band of blocks (what one of 8 ranks renders), on a caller's stream, against the same rows of the full frame
+    full = res["halves"][0]                                                          # ("deep", 8 spp)
+    hnd = hip_scene(gpu, deep, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=8, seed=42, tuning=gpu.RTX_TUNE_HALVES).upload(0)
+    n = int(gpu.abi.load_library(False).rtx_blocks_row_count(h, 8, 3, 8))
+    band = torch.zeros((n, w, 3), dtype=torch.float64, device="cuda:0")
+    s1 = torch.cuda.Stream()
+    hnd.render_blocks(w, h, 8, 3, 8, band.data_ptr(), stream=s1.cuda_stream)
+    s1.synchronize()
+    rows = np.concatenate([np.arange(r, min(r + 8, h)) for r in range(3 * 8, h, 8 * 8)])
+    assert len(rows) == n
+    assert np.array_equal(band.cpu().numpy(), full[rows])
     hnd.close()
 
 
