@@ -145,9 +145,9 @@ enum {
     RTX_TUNE_STAGE2_SLOTS = 1u << 26, /* sphere trees, two stages: stage 2 over ray slots (trace_sph_slots_kernel: a wave owns ~90 rays, a lane
                                         whose walk ends takes the next READY one from LDS, the f64 phase runs for 64 finished walks at once;
                                         round 4's experiment: 12 % fewer instructions, the same time -- LAB_NOTEBOOK R4.3) */
-    RTX_TUNE_HALVES = 1u << 27,      /* sphere trees, two stages: the launch as two halves of the samples in flight on two streams (one
-                                      * drain instead of four) whatever its size; default: launches of <= 2^26 rays */
-    RTX_TUNE_NO_HALVES = 1u << 28,   /* ... never */
+    RTX_TUNE_HALVES = 1u << 27,      /* sphere trees, two stages: the launch as two halves of the samples in flight on two streams
+                                      * (bit-identical, measured slower: not the default) */
+    RTX_TUNE_NO_HALVES = 1u << 28,   /* ... never (today's default, spelled out) */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };

@@ -79,9 +79,10 @@ bool debug_prints()
 #define RTX_GRABS_PER_WAVE 16          // (render_band: grabs a wave makes from the ray queue)
 #endif
 
-// A two-stage sphere launch of at most this many rays runs as two halves in flight (render_band); above it the drain is < 2 % and
-// the halves' second set of queue and stack columns is not worth holding.  Measured: LAB_NOTEBOOK R4.10.
-constexpr uint64_t kHalvesBelowRays = 1ull << 26;
+// A two-stage sphere launch of at most this many rays runs as two halves in flight (render_band).  0: never by default -- the form
+// is bit-identical and SLOWER (LAB_NOTEBOOK R4.11: the drain is nearly empty waves that still hold their slots, not free slots the
+// other half could take); RTX_TUNE_HALVES keeps the experiment one bit away.
+constexpr uint64_t kHalvesBelowRays = 0;
 
 struct RtxSceneHandle_ {
     int device = 0;
@@ -964,14 +965,16 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         rv.n_samples = 0; rv.n_rays = 0; rv.tiles_x = 0;
         RTX_HIP_CHECK(launch_resolve(nullptr, nullptr, d_out_rgb, rv, npix, 0, true, true, stream));
     }
-    // ---- two halves in flight (sphere trees, two stages).  A persistent launch ends with a drain -- the last rays of the last waves
-    // have up to ten dependent rounds to go while the rest of the chip is idle, ~0.7 ms per stage whatever the launch's size: 2 % of a
-    // C2 frame, 12 % of the band one of 8 GPUs renders.  Sample batches are independent (the left fold happens in resolve), so the
-    // launch is cut into two halves of the samples with their own queues, counters and stack columns, on two streams: each stage's
-    // grid fills the chip, so a later kernel's workgroups become resident exactly as an earlier one's leave -- stage 1 of half B runs
-    // in the drain of half A's, stage 2 of A in the drain of B's stage 1, ... and one drain is left at the end instead of four.  The
-    // samples of both halves lie where one launch would have put them: ONE resolve, the same bits (tests).  A launch counts once
-    // (RtxStats.trace_launches), trace_ms is the whole region's time, stage1_ms the time until both halves' primary rays were done.
+    // ---- two halves in flight (sphere trees, two stages; RTX_TUNE_HALVES -- an experiment kept behind its bit, not the default).
+    // A persistent launch ends with a drain: the last rays of the last waves have up to ten dependent rounds to go (~0.7 ms of a
+    // 6.7 ms band of an 8-GPU frame).  Sample batches are independent (the left fold happens in resolve), so the launch is cut into
+    // two halves of the samples with their own queues, counters and stack columns, on two streams (the second at the lowest priority:
+    // the halves take turns, A1 B1 A2 B2), hoping that a later kernel's workgroups become resident as an earlier one's leave.  They
+    // do not, soon enough: a draining wave keeps its slot until its last ray is done, so the chip is full of nearly empty waves, not
+    // of free slots -- and two kernels sharing it are slower than one after the other (band 6.7 -> 7.8 ms, frame 46.7 -> 51.7;
+    // timeline in LAB_NOTEBOOK R4.11).  The samples of both halves lie where one launch would have put them: ONE resolve, the same
+    // bits (tests).  A launch counts once (RtxStats.trace_launches), trace_ms is the whole region's time, stage1_ms the time until
+    // both halves' primary rays were done.
     const uint32_t sph_flags = ((tuning & RTX_TUNE_NO_PACKETS) ? 1u : 0u) | ((tuning & RTX_TUNE_SORT_SURVIVORS) ? 2u : 0u) |
                                ((tuning & RTX_TUNE_STAGE2_POOL) ? 4u : 0u) | ((tuning & RTX_TUNE_STAGE2_PAIR) ? 8u : 0u);   // (lab forms of the sphere kernel)
 #ifdef RTX_LAB
@@ -985,7 +988,11 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
     if (halves) {
         auto &b = h->half2;
         if (!b.stream) {
-            RTX_HIP_CHECK(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+            // the LOWEST priority: when a kernel of each stream is waiting for workgroup slots, the caller's goes first -- the halves
+            // take turns on the chip (A1 B1 A2 B2, each starting in the previous one's drain) instead of sharing it from the start
+            int least = 0, greatest = 0;
+            RTX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            RTX_HIP_CHECK(hipStreamCreateWithPriority(&b.stream, hipStreamNonBlocking, least));
             RTX_HIP_CHECK(hipEventCreateWithFlags(&b.fork, hipEventDisableTiming));
             RTX_HIP_CHECK(hipEventCreateWithFlags(&b.join, hipEventDisableTiming));
             RTX_HIP_CHECK(hipEventCreate(&b.stage1_done));
@@ -1019,7 +1026,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
             r.n_samples = (uint32_t)ns[k];
             r.n_rays = per_sample64 * ns[k];
             r.tiles_x = tiles_x;
-            const uint64_t per_wave = r.n_rays / ((uint64_t)h->n_cus * 16u * RTX_GRABS_PER_WAVE);
+            const uint64_t per_wave = r.n_rays / ((uint64_t)h->n_cus * 16u * (RTX_GRABS_PER_WAVE / 2));   // (half the rays: half the grabs)
             r.grab = (uint32_t)(per_wave >= 512 ? 512 : (per_wave <= 64 ? 64 : (per_wave & ~(uint64_t)63)));
             hipStream_t st = k == 0 ? stream : b.stream;
             RTX_HIP_CHECK(hipMemcpyAsync(k == 0 ? h->d_rv : b.d_rv, &r, sizeof(RowsView), hipMemcpyHostToDevice, st));   // pageable: staged before return
