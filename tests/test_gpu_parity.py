@@ -790,8 +790,8 @@ def test_ab_knobs_keep_the_bits(gpu):
 
 
 def test_two_halves_in_flight_keep_the_bits(gpu, oracle):
-    """A two-stage sphere launch of <= 2^26 rays runs as two halves of the samples on two streams with their own queues, counters
-    and stack columns (render_band: one drain instead of four).  Same image and counters as the single launch (RTX_TUNE_NO_HALVES)
+    """RTX_TUNE_HALVES: a two-stage sphere launch as two halves of the samples on two streams with their own queues, counters and
+    stack columns (render_band; an experiment kept behind its bit).  Same image and counters as the single launch (RTX_TUNE_NO_HALVES)
     and as the exhaustive kernel: even and odd sample counts, a band, a tree deep enough for the HBM stack columns, renders back to
     back on one handle and on two caller streams; the statistics count it as ONE launch and add the halves' counters up."""
     import torch
@@ -803,6 +803,7 @@ def test_two_halves_in_flight_keep_the_bits(gpu, oracle):
     for name, o, spp in (("c2", objs, 8), ("c2", objs, 5), ("c2", objs, 2), ("deep", deep, 8)):
         res = {}
         for tag, tune in (("halves", gpu.RTX_TUNE_HALVES), ("one", gpu.RTX_TUNE_NO_HALVES), ("default", 0)):
+            tune |= gpu.RTX_TUNE_TWO_STAGE                                         # (two stages whatever the ray count)
             hnd = hip_scene(gpu, o, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=spp, seed=42, tuning=tune).upload(0)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
@@ -822,7 +823,8 @@ def test_two_halves_in_flight_keep_the_bits(gpu, oracle):
             assert np.array_equal(a, ex)
     # a band of blocks (what one of 8 ranks renders), on a caller's stream, against the same rows of the full frame
     full = res["halves"][0]                                                          # ("deep", 8 spp)
-    hnd = hip_scene(gpu, deep, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=8, seed=42, tuning=gpu.RTX_TUNE_HALVES).upload(0)
+    hnd = hip_scene(gpu, deep, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=8, seed=42,
+                    tuning=gpu.RTX_TUNE_HALVES | gpu.RTX_TUNE_TWO_STAGE).upload(0)
     n = int(gpu.abi.load_library(False).rtx_blocks_row_count(h, 8, 3, 8))
     band = torch.zeros((n, w, 3), dtype=torch.float64, device="cuda:0")
     s1 = torch.cuda.Stream()
