@@ -63,12 +63,17 @@ constexpr uint32_t kMeshPointLanes = RTX_MESH_POINT_LANES;   // lanes that locat
 #define RTX_MESH_WAVES_Q 3
 #endif
 constexpr uint32_t kMeshWavesQ = RTX_MESH_WAVES_Q;
+// which instances run as fewer, fatter workgroups (kMeshWavesQ per CU: 168 registers per lane instead of 128)
+#ifndef RTX_MESH_WIDE
+#define RTX_MESH_WIDE 0
+#endif
+constexpr bool mesh_wide(bool queue, int plain) { return RTX_MESH_WIDE == 2 ? true : (RTX_MESH_WIDE == 1 ? queue : (queue && plain != 0)); }
 constexpr int kMeshStackQ = 152 / RTX_MESH_WAVES_Q - 1 - 2 * kMeshQueue;      // (37 at 3: 150 KB per CU; at 159 KB only 2 workgroups fit)
 // QUEUE: the rays are not generated here but taken from `src`, a queue of rays in flight at path level 1 (the hybrid of
 // rtx_wavefront.hip: the primary rays of a mesh whose tree exceeds the L2s walk as packets there, and everything after the
 // first hit runs here, where the f64 phases of other waves fill the waits of the per-lane walks).
 template <bool SPILL, int PLAIN, bool QUEUE>
-__global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWaves) void trace_bvh_mesh_kernel(const SceneView *__restrict__ svp,
+__global__ __launch_bounds__(kBvhThreads, mesh_wide(QUEUE, PLAIN) ? kMeshWavesQ : kMeshWaves) void trace_bvh_mesh_kernel(const SceneView *__restrict__ svp,
                                                                                  const RowsView *__restrict__ rvp,
                                                                                  double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                                  unsigned long long *__restrict__ work_counter,
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(kBvhThreads, QUEUE && PLAIN ? kMeshWavesQ : kMeshWa
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
     const unsigned long long n_rays = QUEUE ? *src.count : rv.n_rays;
-    constexpr int STACKN = QUEUE && PLAIN ? kMeshStackQ : kMeshStack;
+    constexpr int STACKN = mesh_wide(QUEUE, PLAIN) ? kMeshStackQ : kMeshStack;
     __shared__ uint32_t lds_stack[STACKN + 1][kBvhThreads];            // + the sink row of the branch-free pushes
     __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];            // candidate entries, then their t_lo
     uint32_t *const ls = &lds_stack[0][0];
@@ -466,7 +471,7 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
                               const MeshRaySource *src)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
-    const bool wide = src && (sv.bvh_flags & 4u) != 0u;          // the queue-fed instance of a pure footprint tree: fewer, fatter workgroups
+    const bool wide = mesh_wide(src != nullptr, (sv.bvh_flags & 4u) != 0u ? 2 : 0);      // fewer, fatter workgroups
     const uint64_t cap = (uint64_t)n_cus * (wide ? kMeshWavesQ : kMeshWaves);
     const uint32_t blocks = (uint32_t)(want < cap ? want : cap);
     if (blocks == 0) return hipSuccess;
