@@ -148,6 +148,8 @@ enum {
     RTX_TUNE_HALVES = 1u << 27,      /* sphere trees, two stages: the launch as two halves of the samples in flight on two streams
                                       * (bit-identical, measured slower: not the default) */
     RTX_TUNE_NO_HALVES = 1u << 28,   /* ... never (today's default, spelled out) */
+    RTX_TUNE_NO_TILE_LISTS = 1u << 29, /* sphere trees, two stages: every packet of primary rays walks the tree (rounds 3's form) instead of
+                                        * running over its tile's list of reachable spheres */
     RTX_TUNE_SORT_SURVIVORS = 1u << 19 /* sphere trees, two stages: stage 2 reads the survivors ordered by the distance at which
                                         their ray leaves the scene's box and by direction octant (a counting sort in between) */
 };
@@ -157,7 +159,7 @@ enum {
                            RTX_TUNE_STAGE2_SLOTS)
 #define RTX_TUNE_KNOWN_MASK (RTX_TUNE_LAB_MASK | RTX_TUNE_NO_TILES | RTX_TUNE_ONE_STAGE | RTX_TUNE_TWO_STAGE | RTX_TUNE_BVH_MEDIAN | \
                              (15u << RTX_TUNE_TRI_LEAF_SHIFT) | (127u << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT | RTX_TUNE_HALVES | \
-                             RTX_TUNE_NO_HALVES)
+                             RTX_TUNE_NO_HALVES | RTX_TUNE_NO_TILE_LISTS)
 
 /* Camera (camera.rs:7-15).  to_world_space / to_cam_space are the three ROWS of each matrix
  * (mat.rs:11-18), row-major.  Only fov, position and to_world_space are read by render
@@ -311,7 +313,8 @@ int32_t rtx_render_blocks(RtxSceneHandle scene, uint32_t width, uint32_t height,
 int32_t rtx_quantize_image_device(const double *d_rgb, uint32_t width, uint32_t height,
                                   uint8_t *d_rgb8, int32_t device, void *stream);
 
-/* Test hook: evaluates one f64 operation per element on the device (op 0: a/b, 1: sqrt(a),
+/* Test hook (lab library; the product returns RTX_ERR_UNSUPPORTED -- same sources and flags, so the arithmetic it shows is the
+ * product's): evaluates one f64 operation per element on the device (op 0: a/b, 1: sqrt(a),
  * 2: sin(a), 3: cos(a), 4 / 5: sincos(a)'s two results; 6: the packet walks' v_writelane -- out[i] = (int)b[0] in lane (int)b[1]
  * of every wave, (int)a[i] elsewhere; 7 / 8: v_min_f64 / v_max_f64 on the raw bits of a[i], b[i] -- the child sort's (key, link)
  * pairs are denormal f64 patterns when the key is +0.0 and must come back bit for bit; 9 / 10: the sin / cos the path itself uses

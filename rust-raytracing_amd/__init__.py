@@ -20,7 +20,7 @@ import numpy as np
 
 from . import abi
 from .abi import (RTX_TUNE_NO_TILES, RTX_TUNE_BVH_CLASSIC, RTX_TUNE_NO_QNODES, RTX_TUNE_NO_PACKETS, RTX_TUNE_WF_PURE, RTX_TUNE_ONE_STAGE,
-                  RTX_TUNE_TWO_STAGE, RTX_TUNE_BVH_MEDIAN, RTX_TUNE_TRI_LEAF_SHIFT, RTX_TUNE_THRESH_SHIFT, RTX_TUNE_SORT_SURVIVORS, RTX_TUNE_PK_LDS_STACK, RTX_TUNE_STAGE2_POOL, RTX_TUNE_STAGE2_PAIR, RTX_TUNE_NO_CUT, RTX_TUNE_BEAMS, RTX_TUNE_INLINE_LEAVES, RTX_TUNE_STAGE2_SLOTS, RTX_TUNE_HALVES, RTX_TUNE_NO_HALVES)
+                  RTX_TUNE_TWO_STAGE, RTX_TUNE_BVH_MEDIAN, RTX_TUNE_TRI_LEAF_SHIFT, RTX_TUNE_THRESH_SHIFT, RTX_TUNE_SORT_SURVIVORS, RTX_TUNE_PK_LDS_STACK, RTX_TUNE_STAGE2_POOL, RTX_TUNE_STAGE2_PAIR, RTX_TUNE_NO_CUT, RTX_TUNE_BEAMS, RTX_TUNE_INLINE_LEAVES, RTX_TUNE_STAGE2_SLOTS, RTX_TUNE_HALVES, RTX_TUNE_NO_HALVES, RTX_TUNE_NO_TILE_LISTS)
 from .abi import (OBJECT_DTYPE, RTX_KERNEL_WAVEFRONT, RTX_KERNEL_AUTO, RTX_KERNEL_BVH, RTX_KERNEL_EXACT, RTX_KERNEL_MIXED, RTX_KERNEL_MIXED_VERIFY, RTX_KERNEL_BVH_REGROUP,
                   RTX_PLANE, RTX_SPHERE, RTX_TRIANGLE, RtxError, load_library)
 
@@ -452,9 +452,11 @@ PATH_STEP_DTYPE = np.dtype([("position", "<f8", (3,)), ("direction", "<f8", (3,)
 
 
 def debug_math(op, a, b=None):
-    """Device evaluation of one f64 op per element (tests only): 0 a/b, 1 sqrt, 2 sin, 3 cos."""
+    """Device evaluation of one f64 op per element (tests only; include/rtx_hip.h, rtx_debug_math): a hook of the lab library -- the
+    same sources and flags as the product, so the arithmetic it shows is the product's."""
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)
     out = np.zeros_like(a)
-    abi.check(load_library().rtx_debug_math(int(op), a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
+    lib = load_library(True)
+    abi.check(lib.rtx_debug_math(int(op), a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size), lib)
     return out

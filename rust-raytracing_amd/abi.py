@@ -28,6 +28,7 @@ RTX_TUNE_STAGE2_PAIR = 1 << 22
 RTX_TUNE_NO_CUT = 1 << 23
 RTX_TUNE_HALVES = 1 << 27
 RTX_TUNE_NO_HALVES = 1 << 28
+RTX_TUNE_NO_TILE_LISTS = 1 << 29
 RTX_TUNE_BEAMS = 1 << 24
 RTX_TUNE_INLINE_LEAVES = 1 << 25
 RTX_TUNE_STAGE2_SLOTS = 1 << 26
@@ -35,7 +36,7 @@ RTX_TUNE_LAB_MASK = (RTX_TUNE_BVH_CLASSIC | RTX_TUNE_NO_QNODES | RTX_TUNE_NO_PAC
                      RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR | RTX_TUNE_BEAMS | RTX_TUNE_INLINE_LEAVES | RTX_TUNE_SORT_SURVIVORS |
                      RTX_TUNE_STAGE2_SLOTS)
 RTX_TUNE_KNOWN_MASK = (RTX_TUNE_LAB_MASK | RTX_TUNE_NO_TILES | RTX_TUNE_ONE_STAGE | RTX_TUNE_TWO_STAGE | RTX_TUNE_BVH_MEDIAN |
-                       (15 << RTX_TUNE_TRI_LEAF_SHIFT) | (127 << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT | RTX_TUNE_HALVES | RTX_TUNE_NO_HALVES)
+                       (15 << RTX_TUNE_TRI_LEAF_SHIFT) | (127 << RTX_TUNE_THRESH_SHIFT) | RTX_TUNE_NO_CUT | RTX_TUNE_HALVES | RTX_TUNE_NO_HALVES | RTX_TUNE_NO_TILE_LISTS)
 RTX_OK, RTX_ERR_INVALID_ARGUMENT, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_OUT_OF_MEMORY = range(6)
 
 # RtxObject, 136 bytes: one entry of Scene.objects (scene.rs:80; object.rs:9-15,78-86)

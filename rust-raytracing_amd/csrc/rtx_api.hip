@@ -101,6 +101,7 @@ struct RtxSceneHandle_ {
     void *wf_state = nullptr;   size_t wf_bytes = 0;       // the wavefront kernels' ray state
     void *pool = nullptr;       size_t pool_bytes = 0;     // (lab) the pool / pair forms of the sphere kernel's stage 2
     void *slots = nullptr;      size_t slots_bytes = 0;    // the slot records of the sphere kernel's stage 2 (trace_sph_slots_kernel)
+    void *tile_lists = nullptr; size_t tile_lists_bytes = 0;   // what each tile's primary rays can reach (build_tile_lists_kernel)
     PathStep *transcript = nullptr; uint32_t *transcript_counts = nullptr; uint32_t transcript_steps = 0;   // (lab) rtx_debug_paths, set for one call
     Counters *counters = nullptr;
     unsigned long long *work_counter = nullptr;
@@ -208,6 +209,7 @@ void free_handle(RtxSceneHandle_ *h)
     if (h->wf_state) (void)hipFree(h->wf_state);
     if (h->pool) (void)hipFree(h->pool);
     if (h->slots) (void)hipFree(h->slots);
+    if (h->tile_lists) (void)hipFree(h->tile_lists);
     if (h->counters) (void)hipFree(h->counters);
     if (h->counters_stage1) (void)hipFree(h->counters_stage1);
     if (h->work_counter) (void)hipFree(h->work_counter);
@@ -925,6 +927,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
+        if ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u)
+            if (int32_t rc = grow(&h->tile_lists, &h->tile_lists_bytes, bvh_spheres_tile_list_bytes(per_sample64))) return rc;
 #ifdef RTX_LAB
         if (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) {
             const size_t a = bvh_spheres_pool2_bytes(h->n_cus), b = bvh_spheres_pair_bytes(h->n_cus);
@@ -1036,7 +1040,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                    k == 0 ? h->work_counter : b.work_counter, reinterpret_cast<uint32_t *>(k == 0 ? h->state : b.state),
                                                    h->n_cus, k == 0 ? h->wf_state : b.queue, sph_flags, st,
                                                    stats ? (k == 0 ? h->counters_stage1 : b.counters_stage1) : nullptr,
-                                                   stats ? (k == 0 ? h->ev[3] : b.stage1_done) : nullptr, nullptr, nullptr));
+                                                   stats ? (k == 0 ? h->ev[3] : b.stage1_done) : nullptr, nullptr, nullptr,
+                                                   k == 0 && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? h->tile_lists : nullptr));
         }
         RTX_HIP_CHECK(hipEventRecord(b.join, b.stream));
         RTX_HIP_CHECK(hipStreamWaitEvent(stream, b.join, 0));
@@ -1117,7 +1122,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                        spheres_two_stage ? h->wf_state : nullptr, sph_flags, stream,
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
                                                        stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr,
-                                                       stage2_slots ? h->slots : nullptr));
+                                                       stage2_slots ? h->slots : nullptr,
+                                                       spheres_two_stage && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? h->tile_lists : nullptr));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,
@@ -1566,6 +1572,10 @@ int32_t rtx_debug_paths(RtxSceneHandle h, uint32_t width, uint32_t height, uint3
 
 int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out, uint64_t n)
 {
+#ifndef RTX_LAB
+    (void)op; (void)a; (void)b; (void)out; (void)n;
+    return fail(RTX_ERR_UNSUPPORTED, "rtx_debug_math: a lab-library hook (librtx_hip_lab.so: the same sources, the same arithmetic)");
+#else
     if (n == 0) return RTX_OK;
     if (!a || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_math: null argument");
     if (usable_device_count() == 0) return fail(RTX_ERR_NO_DEVICE, "no gfx950 device");
@@ -1580,6 +1590,7 @@ int32_t rtx_debug_math(int32_t op, const double *a, const double *b, double *out
     RTX_HIP_CHECK(launch_debug_math(op, d.p[0], d.p[1], d.p[2], n, nullptr));
     RTX_HIP_CHECK(hipMemcpy(out, d.p[2], n * sizeof(double), hipMemcpyDeviceToHost));
     return RTX_OK;
+#endif
 }
 
 }  // extern "C"

@@ -381,6 +381,48 @@ constexpr uint32_t kSphPool = 4u;            // stage 2 as the wave-local pool (
 constexpr uint32_t kSphSortSurvivors = 2u;   // stage 2 reads the survivors ordered by exit distance and octant
 #endif
 
+// One sphere of a leaf against one lane's ray, f32 only: the candidate test and bounds of sphere_step (rtx_traverse.h).  A sphere the
+// exact test cannot be excluded for joins the lane's candidate queue (LDS: {local index, t_lo}); a certain hit tightens best_up.
+__device__ __forceinline__ void sph_packet_leaf_test(const float4 rec, const uint32_t prim, const SphereRay &sr, uint32_t *lq, uint32_t tid,
+                                 float &best_up, uint32_t &qcnt, bool &overflow)
+{
+    const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
+    const float bq = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
+    const float lx = __builtin_fmaf(-bq, sr.dx, ox), ly = __builtin_fmaf(-bq, sr.dy, oy), lz = __builtin_fmaf(-bq, sr.dz, oz);
+    const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
+    const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
+    const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
+    const float Dp = Dl + G;
+    if (Dp >= 0.0f) {                                      // the exact test cannot be excluded (rtx_traverse.h, sphere_step)
+        const float tlo = bq - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
+        const float Dm = Dl - G;
+        const float thi = Dm > 0.0f ? bq - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
+        if (tlo <= best_up && !(thi < 0.0f)) {
+            if (tlo > sr.K) best_up = fminf(best_up, thi);
+            if (qcnt == (uint32_t)kSphQueue) {             // drop the entries a later certain hit has overtaken
+                uint32_t w = 0;
+#pragma unroll
+                for (int e = 0; e < kSphQueue; ++e) {
+                    const uint32_t ie = lq[(size_t)e * kBvhThreads + tid];
+                    const uint32_t te = lq[(size_t)(kSphQueue + e) * kBvhThreads + tid];
+                    if (__uint_as_float(te) <= best_up) {
+                        lq[(size_t)w * kBvhThreads + tid] = ie;
+                        lq[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
+                        w += 1;
+                    }
+                }
+                qcnt = w;
+            }
+            if (qcnt == (uint32_t)kSphQueue) overflow = true;   // (the segment then tests every sphere exactly)
+            else {
+                lq[(size_t)qcnt * kBvhThreads + tid] = prim;
+                lq[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
+                qcnt += 1;
+            }
+        }
+    }
+}
+
 // The walk of one tile.  SGN < 8: every ray of the tile points into octant SGN (bit a set: direction component a is
 // negative), so the near / far plane of each slab is known at compile time; SGN == 8: mixed signs, min / max per slab.
 //
@@ -453,41 +495,7 @@ __device__ __forceinline__ void sph_packet_walk(const PkConst4 cnodes, const PkC
                     const float4 rec = csph[first + j];                    // {c - centre, r}
                     const uint32_t prim = cprims[first + j];
                     if (!in) continue;
-                    const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
-                    const float bq = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
-                    const float lx = __builtin_fmaf(-bq, sr.dx, ox), ly = __builtin_fmaf(-bq, sr.dy, oy), lz = __builtin_fmaf(-bq, sr.dz, oz);
-                    const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
-                    const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
-                    const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
-                    const float Dp = Dl + G;
-                    if (Dp >= 0.0f) {                                      // the exact test cannot be excluded (rtx_traverse.h, sphere_step)
-                        const float tlo = bq - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
-                        const float Dm = Dl - G;
-                        const float thi = Dm > 0.0f ? bq - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
-                        if (tlo <= best_up && !(thi < 0.0f)) {
-                            if (tlo > sr.K) best_up = fminf(best_up, thi);
-                            if (qcnt == (uint32_t)kSphQueue) {             // drop the entries a later certain hit has overtaken
-                                uint32_t w = 0;
-#pragma unroll
-                                for (int e = 0; e < kSphQueue; ++e) {
-                                    const uint32_t ie = lq[(size_t)e * kBvhThreads + tid];
-                                    const uint32_t te = lq[(size_t)(kSphQueue + e) * kBvhThreads + tid];
-                                    if (__uint_as_float(te) <= best_up) {
-                                        lq[(size_t)w * kBvhThreads + tid] = ie;
-                                        lq[(size_t)(kSphQueue + w) * kBvhThreads + tid] = te;
-                                        w += 1;
-                                    }
-                                }
-                                qcnt = w;
-                            }
-                            if (qcnt == (uint32_t)kSphQueue) overflow = true;   // (the segment then tests every sphere exactly)
-                            else {
-                                lq[(size_t)qcnt * kBvhThreads + tid] = prim;
-                                lq[(size_t)(kSphQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
-                                qcnt += 1;
-                            }
-                        }
-                    }
+                    sph_packet_leaf_test(rec, prim, sr, lq, tid, best_up, qcnt, overflow);
                 }
             }
 #pragma unroll
@@ -569,12 +577,126 @@ __device__ __forceinline__ void sph_packet_walk(const PkConst4 cnodes, const PkC
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Tile lists: what the primary rays of an 8x8 pixel tile can hit, found ONCE per tile instead of once per packet.
+//
+// Every ray of a tile, whatever its sample's jitter, starts in the box O = cam_pos + [0, non_focal_offset]^3 and goes through the box
+// T = hull of the tile's focal points + [0, focal_offset]^3 (scene.rs:202-205): p(u) = o + u (t - o), u >= 0, distance along the ray
+// = u |t - o|.  With interval arithmetic per axis, p_a(u) lies in [omin_a + u (tmin_a - omax_a), omax_a + u (tmax_a - omin_a)] for
+// every u >= 0 -- a "ray" with an interval origin and an interval direction, and a slab test against a node's box is six linear
+// inequalities in u.  One thread per tile walks the tree with that test and writes down every sphere whose leaf box the beam can
+// enter: {the leaf's f32 record, its index, a lower bound of the distance at which any ray of the tile can enter the box}, sorted
+// by that bound.  C2: ~10 spheres per tile where a packet's walk visits ~33 nodes -- for each of the tile's 64 samples.
+// The packet kernel then runs the walk's leaf test over the list, and stops at the first entry whose bound lies beyond every
+// lane's nearest certain hit.  The list is a superset of what any walk of the tile would reach (the beam contains every ray; the
+// boxes are the walk's own), the candidates' exact tests decide as before: same bits.  A tile whose list would exceed kTileListCap
+// entries (the camera inside a cluster, focal_length ~ 0, NaNs), or whose walk exceeds the builder's stack, keeps the packet walk.
+constexpr uint32_t kTileListCap = 64;                     // entries per tile
+constexpr uint32_t kTileListWalk = 0xFFFFFFFFu;           // count: this tile walks
+struct TileEntry { float4 rec; uint32_t prim; float t_lb; uint32_t pad0, pad1; };      // 32 bytes: one s_load_dwordx8
+static_assert(sizeof(TileEntry) == 32, "TileEntry");
+struct TileLists {
+    uint32_t *count;                                      // [tiles]; null: no lists (every tile walks)
+    TileEntry *entries;                                   // [tiles][kTileListCap]
+};
+
+__global__ __launch_bounds__(256) void build_tile_lists_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
+                                                               const float4 *__restrict__ nodes, const float4 *__restrict__ sphere_f32,
+                                                               const uint32_t *__restrict__ sphere_prims, TileLists tl, uint32_t n_tiles)
+{
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    // ---- the beam: O, T (the hull of the tile's pixels that exist), D = T - O outward-rounded, the shortest |t - o|
+    const double nfo = sv.non_focal_offset, fo = sv.focal_offset;
+    const double cam[3] = { sv.cam_pos.x, sv.cam_pos.y, sv.cam_pos.z };
+    double omin[3], omax[3], tmin[3], tmax[3];
+    for (int a = 0; a < 3; ++a) {
+        omin[a] = cam[a] + fmin(0.0, nfo); omax[a] = cam[a] + fmax(0.0, nfo);     // rnd in [0, 1): monotone roundings keep the bounds
+        tmin[a] = __builtin_inf(); tmax[a] = -__builtin_inf();
+    }
+    bool any = false;
+    for (uint32_t j = 0; j < 64u; ++j) {
+        uint32_t pl, smp;
+        if (!ray_index_to_pixel_tiled(rv, (uint64_t)tile * 64u + j, pl, smp)) continue;
+        const V3 f = primary_focal_point(sv, rv, pl);
+        const double fp[3] = { f.x, f.y, f.z };
+        for (int a = 0; a < 3; ++a) {
+            tmin[a] = fmin(tmin[a], fp[a] + fmin(0.0, fo));
+            tmax[a] = fmax(tmax[a], fp[a] + fmax(0.0, fo));
+        }
+        any = true;
+    }
+    if (!any) { tl.count[tile] = 0u; return; }            // (a tile of padding only: no ray looks at it)
+    double dlo[3], dhi[3], gap2 = 0.0;
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = tmin[a] - omax[a], hi = tmax[a] - omin[a];
+        const double w = (fabs(lo) + fabs(hi)) * 1e-12 + 1e-300;
+        dlo[a] = lo - w; dhi[a] = hi + w;
+        const double g = fmax(0.0, fmax(tmin[a] - omax[a], omin[a] - tmax[a]));
+        gap2 += g * g;
+        ok = ok && isfinite(dlo[a]) && isfinite(dhi[a]) && isfinite(omin[a]) && isfinite(omax[a]);
+    }
+    const double lmin = sqrt(gap2) * (1.0 - 1e-9);
+    ok = ok && (sv.bvh_root & kBvhFlatNode) == 0u;
+    // ---- the walk: every leaf box the beam can enter
+    TileEntry *const out = tl.entries + (size_t)tile * kTileListCap;
+    uint32_t stack[64];
+    uint32_t sp = 0, n = 0, node = sv.bvh_root;
+    while (ok && node != 0xFFFFFFFFu) {
+        const float4 *np = nodes + 8 * (size_t)node;
+        node = 0xFFFFFFFFu;
+        for (int c = 0; c < 4 && ok; ++c) {
+            const float4 a = np[c], b = np[4 + c];
+            const uint32_t link = __float_as_uint(a.w), cnt = __float_as_uint(b.w);
+            if (cnt == 0xFFFFFFFFu) continue;             // an empty slot
+            const double lo[3] = { (double)a.x, (double)a.y, (double)a.z }, hi[3] = { (double)b.x, (double)b.y, (double)b.z };
+            double u0 = 0.0, u1 = __builtin_inf();
+            bool miss = false;
+            for (int k = 0; k < 3; ++k) {
+                // omin + u dlo <= hi
+                if (dlo[k] > 0.0) u1 = fmin(u1, (hi[k] - omin[k]) / dlo[k]);
+                else if (dlo[k] < 0.0) u0 = fmax(u0, (hi[k] - omin[k]) / dlo[k]);
+                else if (omin[k] > hi[k]) miss = true;
+                // omax + u dhi >= lo
+                if (dhi[k] > 0.0) u0 = fmax(u0, (lo[k] - omax[k]) / dhi[k]);
+                else if (dhi[k] < 0.0) u1 = fmin(u1, (lo[k] - omax[k]) / dhi[k]);
+                else if (omax[k] < lo[k]) miss = true;
+            }
+            if (!(u0 == u0) || !(u1 == u1)) { ok = false; break; }          // NaN (inf - inf, 0 / 0): no list for this tile
+            if (miss || u0 * (1.0 - 1e-9) > u1 * (1.0 + 1e-9) + 1e-300) continue;
+            if (cnt == 0u) {                              // interior child
+                if (sp == 64u) { ok = false; break; }
+                stack[sp++] = link;
+            } else if ((cnt & kBvhTriLeaf) == 0u) {       // sphere leaf: `cnt` records from `link`
+                const float t_lb = round_down_f32_dev(u0 * lmin * (1.0 - 1e-6) - 1e-30);
+                for (uint32_t j = 0; j < (cnt & 0xFFFFu); ++j) {
+                    if (n == kTileListCap) { ok = false; break; }
+                    // insertion by t_lb (ascending; equal bounds keep their order of arrival)
+                    uint32_t k = n;
+                    while (k > 0u && out[k - 1u].t_lb > t_lb) { out[k] = out[k - 1u]; --k; }
+                    TileEntry e;
+                    e.rec = sphere_f32[link + j]; e.prim = sphere_prims[link + j]; e.t_lb = t_lb; e.pad0 = e.pad1 = 0u;
+                    out[k] = e;
+                    ++n;
+                }
+            } else {
+                ok = false;                               // (a sphere tree holds no triangle leaves)
+            }
+        }
+        if (ok && sp != 0u) node = stack[--sp];
+    }
+    tl.count[tile] = ok ? n : kTileListWalk;
+}
+
 __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kernel(const SceneView *__restrict__ svp,
                                                                                   const RowsView *__restrict__ rvp,
                                                                                   double *__restrict__ samples, Counters *__restrict__ ctr,
                                                                                   unsigned long long *__restrict__ work_counter,
                                                                                   const float4 *__restrict__ nodes, const LeafArrays la,
-                                                                                  const SphQueue sq)
+                                                                                  const SphQueue sq, const TileLists tl)
 {
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
@@ -633,7 +755,23 @@ __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kerne
             }
         }
         const unsigned long long wm = __ballot(walked);
-        if (wm != 0ull) {
+        // the tile's list, if it has one (wave-uniform: scalar loads)
+        uint32_t list_n = kTileListWalk;
+        const uint32_t tile_of = __builtin_amdgcn_readfirstlane((uint32_t)(((uint32_t)my - smp * rv.div_per_sample.d) >> 6));
+        if (tl.count != nullptr && wm != 0ull) list_n = pk_const(tl.count)[tile_of];
+        if (wm != 0ull && list_n != kTileListWalk) {
+            const PkConst4 ent = pk_const(reinterpret_cast<const float4 *>(tl.entries + (size_t)tile_of * kTileListCap));
+            for (uint32_t k = 0; k < list_n; ++k) {
+                const float4 rec = ent[2 * k], tail = ent[2 * k + 1];
+                const float t_lb = tail.y;
+                const bool in = walked && t_lb <= best_up;
+                if (__ballot(in) == 0ull) break;          // sorted by t_lb: nothing further can beat any lane's certain hit
+                if (in) {
+                    nleaf += 1;
+                    sph_packet_leaf_test(rec, __float_as_uint(tail.x), sr, lq, tid, best_up, qcnt, overflow);
+                }
+            }
+        } else if (wm != 0ull) {
             const uint32_t my_sgn = (q.ix < 0.0f ? 1u : 0u) | (q.iy < 0.0f ? 2u : 0u) | (q.iz < 0.0f ? 4u : 0u);
             const uint32_t sgn = __builtin_amdgcn_readlane(my_sgn, (int)(__ffsll((long long)wm) - 1));
             const uint32_t oct = __ballot(walked && my_sgn != sgn) == 0ull ? sgn : 8u;      // 8: the tile straddles an axis
@@ -750,6 +888,13 @@ static uint64_t sph_queue_capacity(uint64_t n_rays, int n_cus)
     return n_rays + (uint64_t)n_cus * wpc * (kBvhThreads / 64) * kSphQueueChunk + kSphQueueChunk;
 }
 
+// the tile lists of a launch: a count per tile (padded to 256 bytes) + kTileListCap entries of 32 bytes per tile
+size_t bvh_spheres_tile_list_bytes(uint64_t rays_per_sample)
+{
+    const uint64_t n_tiles = rays_per_sample >> 6;
+    return (size_t)(((n_tiles * sizeof(uint32_t) + 255) & ~(uint64_t)255) + n_tiles * kTileListCap * sizeof(TileEntry));
+}
+
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus)
 {
     const uint64_t cap = sph_queue_capacity(n_rays, n_cus);
@@ -779,7 +924,7 @@ bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled)
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot, hipEvent_t stage1_done,
-                                    void *pool_mem, void *slots_mem)
+                                    void *pool_mem, void *slots_mem, void *tile_list_mem)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -838,8 +983,18 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
     {
         const uint64_t pcap = (uint64_t)n_cus * kSpkWaves;
         const uint32_t pblocks = (uint32_t)(want < pcap ? want : pcap);
+        TileLists tl{};
+        if (tile_list_mem && tiled && (sv.tuning & RTX_TUNE_NO_TILE_LISTS) == 0u) {
+            // what each tile's primary rays can hit, once per tile (build_tile_lists_kernel); the packets then run over the lists
+            const uint32_t n_tiles = (uint32_t)((rv.n_rays / rv.n_samples) >> 6);
+            tl.count = reinterpret_cast<uint32_t *>(tile_list_mem);
+            tl.entries = reinterpret_cast<TileEntry *>(static_cast<char *>(tile_list_mem) + (((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255));
+            hipLaunchKernelGGL(build_tile_lists_kernel, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, d_sv, d_rv, nodes, la.sphere_f32,
+                               la.sphere_prims, tl, n_tiles);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(trace_sph_packet_kernel, dim3(pblocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
-                           nodes, la, sq);
+                           nodes, la, sq, tl);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (stage1_snapshot && (e = hipMemcpyAsync(stage1_snapshot, counters, sizeof(Counters) * kCounterShards, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;

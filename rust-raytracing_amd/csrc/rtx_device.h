@@ -188,6 +188,24 @@ __device__ __forceinline__ void store_sample(double *__restrict__ samples, const
     *rec = make_double4(c.x, c.y, c.z, 0.0);
 }
 
+// focal_point of a local pixel: get_ray_dir (scene.rs:213-222, with the host-computed trig values) and scene.rs:203
+__device__ __forceinline__ V3 primary_focal_point(const SceneView &sv, const RowsView &rv, uint32_t pl)
+{
+    const uint32_t k = fastdiv(pl, rv.div_width);        // local row
+    const uint32_t x = pl - k * rv.width;
+    const V3 cam_space_dir = mk(rv.sin_x[x], rv.sin_y[k], rv.cos_x[x] * rv.cos_y[k]);                   // scene.rs:216-221
+    const V3 ray_dir = mk(dot(cam_space_dir, sv.to_world_x), dot(cam_space_dir, sv.to_world_y),
+                          dot(cam_space_dir, sv.to_world_z));                                            // mat/mul.rs:42-50
+    return vadd(sv.cam_pos, vmuls(ray_dir, sv.focal_length));                                            // scene.rs:203
+}
+
+__device__ __forceinline__ float round_down_f32_dev(double x)
+{
+    float f = (float)x;
+    if ((double)f > x) f = __uint_as_float(f > 0.0f ? __float_as_uint(f) - 1u : (f < 0.0f ? __float_as_uint(f) + 1u : 0x80000001u));
+    return f;
+}
+
 // render_pixel's per-sample prologue (scene.rs:196-207) + get_ray_dir (scene.rs:213-222).
 __device__ __forceinline__ void gen_primary(const SceneView &sv, const RowsView &rv, uint32_t pl, uint32_t sample,
                                             RayState &r)
@@ -196,15 +214,11 @@ __device__ __forceinline__ void gen_primary(const SceneView &sv, const RowsView 
     uint32_t x = pl - k * rv.width;
     uint32_t y = image_row(rv, k);
     uint64_t pix = (uint64_t)y * rv.width + x;     // index in the FULL image keys the RNG
-    // scene.rs:216-221 with the host-computed trig values
-    V3 cam_space_dir = mk(rv.sin_x[x], rv.sin_y[k], rv.cos_x[x] * rv.cos_y[k]);
-    V3 ray_dir = mk(dot(cam_space_dir, sv.to_world_x), dot(cam_space_dir, sv.to_world_y),
-                    dot(cam_space_dir, sv.to_world_z));                  // mat/mul.rs:42-50
     r.key = rng_key(sv.seed, pix, sample);
     V3 rnd1;                                                             // vector.rs:29-35: x, y, z in order
     rnd1.x = rng_u01(r.key, 0); rnd1.y = rng_u01(r.key, 1); rnd1.z = rng_u01(r.key, 2);
     V3 ray_position = vadd(sv.cam_pos, vmuls(rnd1, sv.non_focal_offset));      // scene.rs:202
-    V3 focal_point = vadd(sv.cam_pos, vmuls(ray_dir, sv.focal_length));        // scene.rs:203
+    V3 focal_point = primary_focal_point(sv, rv, pl);                          // scene.rs:203, 213-222
     V3 rnd2;
     rnd2.x = rng_u01(r.key, 3); rnd2.y = rng_u01(r.key, 4); rnd2.z = rng_u01(r.key, 5);
     V3 target_point = vadd(focal_point, vmuls(rnd2, sv.focal_offset));         // scene.rs:204

@@ -599,6 +599,7 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const T *__restrict__
     full[i] = parts[((uint64_t)p * cap_rows + k) * row_vals + c];
 }
 
+#ifdef RTX_LAB
 __global__ void debug_math_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -622,6 +623,7 @@ __global__ void debug_math_kernel(int op, const double *a, const double *b, doub
     }
     out[i] = r;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // launchers
@@ -769,11 +771,13 @@ hipError_t launch_deinterleave_u8(const uint8_t *parts, uint8_t *full, uint32_t 
     return hipGetLastError();
 }
 
+#ifdef RTX_LAB
 hipError_t launch_debug_math(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(debug_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, op, a, b, out, n);
     return hipGetLastError();
 }
+#endif
 
 }  // namespace rtx

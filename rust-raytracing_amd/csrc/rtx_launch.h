@@ -40,13 +40,15 @@ size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
 // survive their first hit in a second one fed from a queue of 64-byte records), or null: one launch.  A survivor the queue
 // cannot take raises counters[1].pad_ (the launch's watchdog word, reported by the API).
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
+size_t bvh_spheres_tile_list_bytes(uint64_t rays_per_sample);
 // may a launch run in two stages?  The product's stage 1 exists as packets only (tiled ray queue, a tree the wave-uniform stack
 // holds); the lab library falls back to per-lane primary rays (MODE 1) and always may.
 bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled);
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot = nullptr,
-                                    hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr, void *slots_mem = nullptr);
+                                    hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr, void *slots_mem = nullptr,
+                                    void *tile_list_mem = nullptr);      // tile_list_mem: bvh_spheres_tile_list_bytes(rays per sample) bytes, or null: every tile walks
 #ifdef RTX_LAB
 // slots_mem: bvh_spheres_slots_bytes(n_cus) bytes of device memory, or null: with it stage 2 of the two-stage form runs over ray
 // slots (trace_sph_slots_kernel: the f64 path state of the rays in flight, one 128-byte record per slot)
@@ -141,6 +143,8 @@ hipError_t launch_quantize_values(const double *rgb, uint8_t *rgb8, uint64_t n, 
 hipError_t launch_trace_transcript(const SceneView *d_sv, const RowsView *d_rv, const RowsView &rv, PathStep *steps, uint32_t *counts,
                                    uint32_t max_steps, hipStream_t stream);
 #endif
+#ifdef RTX_LAB
 hipError_t launch_debug_math(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
+#endif
 
 }  // namespace rtx

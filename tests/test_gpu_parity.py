@@ -759,7 +759,8 @@ def test_ab_knobs_keep_the_bits(gpu):
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_INLINE_LEAVES, gpu.RTX_TUNE_INLINE_LEAVES | gpu.RTX_TUNE_NO_CUT,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_STAGE2_SLOTS, gpu.RTX_TUNE_STAGE2_SLOTS,
              gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_HALVES, gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_HALVES,
-             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_HALVES | gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_HALVES]
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_HALVES | gpu.RTX_TUNE_NO_PACKETS, gpu.RTX_TUNE_HALVES,
+             gpu.RTX_TUNE_TWO_STAGE | gpu.RTX_TUNE_NO_TILE_LISTS, gpu.RTX_TUNE_NO_TILE_LISTS]
     # a knob with a RTX_TUNE_LAB_MASK bit renders through librtx_hip_lab.so (the product library refuses it, below); the others
     # through the product library and, as LabKernel ids, through the lab library's kernel family of each id
     L = gpu.LabKernel
@@ -833,6 +834,75 @@ def test_two_halves_in_flight_keep_the_bits(gpu, oracle):
     rows = np.concatenate([np.arange(r, min(r + 8, h)) for r in range(3 * 8, h, 8 * 8)])
     assert len(rows) == n
     assert np.array_equal(band.cpu().numpy(), full[rows])
+    hnd.close()
+
+
+def test_tile_lists_of_the_primary_rays_keep_the_bits(gpu, oracle):
+    """Stage 1 of the sphere path: what an 8x8 tile's primary rays can hit is found once per tile (build_tile_lists_kernel: a walk
+    with an interval origin and an interval direction) and every packet of the tile runs the walk's leaf test over that list
+    instead of walking (rtx_bvh_spheres.hip).  Same image and segment count as the packets' own walks (RTX_TUNE_NO_TILE_LISTS) and
+    as the exhaustive kernel, where the list is short, where it overflows (a dense cluster: those tiles walk), where both happen in
+    one frame, with the camera inside the cloud and far outside the tree's range, for partial tiles, a band of blocks, lens
+    settings that degenerate the beam (focal length 0 and negative, no jitter, negative and huge offsets), planes and loose
+    triangles next to the tree.  The lists must also have been USED: fewer box tests than the walks."""
+    import torch
+    from rust_raytracing_amd import scenes
+    T = gpu.RTX_TUNE_TWO_STAGE
+    rng = np.random.default_rng(5)
+
+    def cluster(n, centre, spread, rmin, rmax, seed):
+        o = scenes.random_spheres(n, seed).copy()
+        u = np.random.default_rng(seed).random((n, 4))
+        o["geom"][:, :3] = np.asarray(centre) + (u[:, :3] - 0.5) * spread
+        o["geom"][:, 3] = rmin + (rmax - rmin) * u[:, 3]
+        return o
+
+    sparse = scenes.random_spheres(10000, 1)
+    dense = cluster(3000, (14.0, 0.0, 0.0), (6.0, 16.0, 9.0), 0.4, 1.5, 8)              # ~200 spheres behind every tile: the lists overflow
+    half = np.concatenate([cluster(2500, (14.0, -6.0, 0.0), (6.0, 8.0, 9.0), 0.4, 1.5, 9), sparse[:4000]])
+    extras = np.concatenate([sparse[:3000], scenes.mixed_scene(1, 6, 2, seed=3)])
+    cam_in = ((60.0, 3.0, -2.0), (0.7, 0.6, 0.2), 1.3)
+    cam_far = ((-3.0e6, 10.0, 5.0), (1.0, 0.0, 0.0), 0.0003)
+    cases = [("sparse", sparse, 512, 288, scenes.CAMERA, {}), ("partial tiles", sparse, 501, 283, scenes.CAMERA, {}),
+             ("dense", dense, 256, 144, scenes.CAMERA, {}), ("half dense", half, 384, 216, scenes.CAMERA, {}),
+             ("inside", sparse, 384, 216, cam_in, {}), ("far outside", sparse, 256, 144, cam_far, {}),
+             ("planes and loose triangles", extras, 384, 216, scenes.CAMERA, {}),
+             ("focal length 0", sparse, 256, 144, scenes.CAMERA, dict(focal_length=0.0)),
+             ("focal length < 0", sparse, 256, 144, scenes.CAMERA, dict(focal_length=-4.0)),
+             ("pinhole", sparse, 256, 144, scenes.CAMERA, dict(focal_offset=0.0, non_focal_offset=0.0)),
+             ("negative offsets", sparse, 256, 144, scenes.CAMERA, dict(focal_offset=-0.3, non_focal_offset=-0.2)),
+             ("wide aperture", sparse, 256, 144, scenes.CAMERA, dict(non_focal_offset=5.0, focal_length=30.0))]
+    used = 0
+    for name, objs, w, h, cam, lens in cases:
+        out = {}
+        for tag, kern, tune in (("lists", gpu.RTX_KERNEL_AUTO, T), ("walks", gpu.RTX_KERNEL_AUTO, T | gpu.RTX_TUNE_NO_TILE_LISTS),
+                                ("exact", gpu.RTX_KERNEL_EXACT, 0)):
+            spp = 2
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=spp, seed=11, tuning=tune, **lens).upload(0)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            hnd.close()
+            out[tag] = (buf.cpu().numpy(), st)
+        a, sa = out["lists"]
+        assert sa.kernel == gpu.RTX_KERNEL_BVH and sa.stage1_ms > 0, name
+        for other in ("walks", "exact"):
+            b, sb = out[other]
+            assert np.array_equal(a, b, equal_nan=True) and sa.segments == sb.segments, (name, other)
+        assert sa.stage1_box_tests <= out["walks"][1].stage1_box_tests, name
+        used += sa.stage1_box_tests < 0.5 * out["walks"][1].stage1_box_tests
+        if name == "dense":
+            assert sa.stage1_box_tests > 0.5 * out["walks"][1].stage1_box_tests          # (its tiles walk: the lists overflowed)
+    assert used >= 6
+    # a band of blocks on a caller's stream
+    hnd = hip_scene(gpu, sparse, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=2, seed=11, tuning=T).upload(0)
+    w, h = 512, 288
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    hnd.render_rows(w, h, 0, 1, h, full.data_ptr())
+    n = int(gpu.abi.load_library(False).rtx_blocks_row_count(h, 8, 5, 8))
+    band = torch.zeros((n, w, 3), dtype=torch.float64, device="cuda:0")
+    hnd.render_blocks(w, h, 8, 5, 8, band.data_ptr())
+    rows = np.concatenate([np.arange(r, min(r + 8, h)) for r in range(5 * 8, h, 8 * 8)])
+    assert np.array_equal(band.cpu().numpy(), full.cpu().numpy()[rows])
     hnd.close()
 
 
