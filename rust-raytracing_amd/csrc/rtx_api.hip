@@ -822,14 +822,15 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         size_t cap_bytes = h->scratch_limit ? h->scratch_limit : kDefaultScratchBytes;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t mine = h->samples_bytes + h->wf_bytes;
+            const size_t mine = h->samples_bytes + h->wf_bytes + h->tile_lists_bytes;
             const size_t avail = (free_b + mine) / 4 * 3;
             if (cap_bytes > avail) cap_bytes = avail;
         } else (void)hipGetLastError();
         // what a launch allocates whatever its batch -- the survivors' queue's chunk per resident wave and counters, the
         // wavefront form's level counters and overflow list, the HBM stack columns -- comes off the cap first; the floor is ONE
         // sample per launch (a frame cannot be cut finer), which a limit below that size gets with the overhead on top
-        const uint64_t fixed = (sph2 ? (uint64_t)bvh_spheres_queue_bytes(0, h->n_cus) + bvh_spheres_spill_bytes(h->sv, h->n_cus) : 0) +
+        const uint64_t fixed = (sph2 ? (uint64_t)bvh_spheres_queue_bytes(0, h->n_cus) + bvh_spheres_spill_bytes(h->sv, h->n_cus) +
+                                           ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? (uint64_t)bvh_spheres_tile_list_bytes(per_sample64) : 0) : 0) +
                                (kernel == RTX_KERNEL_WAVEFRONT ? (uint64_t)wavefront_state_bytes(0, 1) + wavefront_spill_bytes(h->sv, h->n_cus) : 0) +
                                (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY ? (uint64_t)mixed_state_bytes(h->n_cus) : 0);
         const uint64_t room = cap_bytes > fixed ? cap_bytes - fixed : 0;
@@ -1041,7 +1042,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                    h->n_cus, k == 0 ? h->wf_state : b.queue, sph_flags, st,
                                                    stats ? (k == 0 ? h->counters_stage1 : b.counters_stage1) : nullptr,
                                                    stats ? (k == 0 ? h->ev[3] : b.stage1_done) : nullptr, nullptr, nullptr,
-                                                   k == 0 && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? h->tile_lists : nullptr));
+                                                   nullptr));                   // (the halves' packets walk: no tile lists in this form)
         }
         RTX_HIP_CHECK(hipEventRecord(b.join, b.stream));
         RTX_HIP_CHECK(hipStreamWaitEvent(stream, b.join, 0));

@@ -556,7 +556,7 @@ def test_spheres_kernel_paths(gpu, oracle):
     # partial tiles, and with a scratch cap that cuts the frame into several launches
     big = {}
     for name, tune, limit in (("two", 0, 0), ("two_lanes", gpu.RTX_TUNE_NO_PACKETS, 0), ("one", gpu.RTX_TUNE_ONE_STAGE, 0),
-                              ("two_batched", 0, 150 << 20)):
+                              ("two_batched", 0, 150 << 20), ("two_walks", gpu.RTX_TUNE_NO_TILE_LISTS, 0)):
         hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_BVH, rays_per_pixel=2, seed=42, tuning=tune).upload(0)
         hnd.set_scratch_limit(limit)
         buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
@@ -564,9 +564,10 @@ def test_spheres_kernel_paths(gpu, oracle):
         hnd.close()
         big[name] = (buf.cpu().numpy(), st.segments, st.trace_launches, st.box_tests)
     assert big["two"][2] == 1 and big["one"][2] == 1 and big["two_batched"][2] == 2
-    for name in ("two_lanes", "one", "two_batched"):
+    for name in ("two_lanes", "one", "two_batched", "two_walks"):
         assert np.array_equal(big["two"][0], big[name][0]) and big["two"][1] == big[name][1], name
-    assert big["two"][3] > big["two_lanes"][3]                                   # (a packet tests the union of its rays' nodes)
+    assert big["two_walks"][3] > big["two_lanes"][3]                             # (a packet tests the union of its rays' nodes)
+    assert big["two"][3] < big["two_lanes"][3]                                   # (... unless it runs over its tile's list: no box tests)
     hnd = hip_scene(gpu, c2, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_EXACT, rays_per_pixel=2, seed=42).upload(0)
     buf = torch.zeros((997, 1203, 3), dtype=torch.float64, device="cuda:0")
     ste = hnd.render_rows(1203, 997, 0, 1, 997, buf.data_ptr())
@@ -803,8 +804,8 @@ def test_two_halves_in_flight_keep_the_bits(gpu, oracle):
     w, h = 512, 288
     for name, o, spp in (("c2", objs, 8), ("c2", objs, 5), ("c2", objs, 2), ("deep", deep, 8)):
         res = {}
-        for tag, tune in (("halves", gpu.RTX_TUNE_HALVES), ("one", gpu.RTX_TUNE_NO_HALVES), ("default", 0)):
-            tune |= gpu.RTX_TUNE_TWO_STAGE                                         # (two stages whatever the ray count)
+        for tag, tune in (("halves", gpu.RTX_TUNE_HALVES), ("one", gpu.RTX_TUNE_NO_HALVES | gpu.RTX_TUNE_NO_TILE_LISTS), ("default", 0)):
+            tune |= gpu.RTX_TUNE_TWO_STAGE                                         # (two stages whatever the ray count; the halves walk: no tile lists)
             hnd = hip_scene(gpu, o, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=spp, seed=42, tuning=tune).upload(0)
             buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
             st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
@@ -1328,7 +1329,7 @@ def test_c4_shaped_band_of_one_rank(gpu, oracle):
     got, st = res["two"]
     assert st.kernel == gpu.RTX_KERNEL_BVH and st.trace_launches == 2 and st.primary_rays == n * w * 4
     assert np.array_equal(got, res["one"][0]) and st.segments == res["one"][1].segments
-    assert st.box_tests > res["one"][1].box_tests             # stage 1 ran as packets (a packet tests the union of its rays' nodes)
+    assert st.stage1_ms > 0 and st.box_tests < res["one"][1].box_tests      # stage 1 ran as packets over their tiles' lists: no box tests there
     osc = oracle.make_scene(objs, scenes.CAMERA, rays_per_pixel=4, seed=42)
     assert n == 272 and part.rows[0] == 24 and part.rows[8] == 88
     for k in (0, 133, 271):
