@@ -831,7 +831,9 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         // sample per launch (a frame cannot be cut finer), which a limit below that size gets with the overhead on top
         const uint64_t fixed = (sph2 ? (uint64_t)bvh_spheres_queue_bytes(0, h->n_cus) + bvh_spheres_spill_bytes(h->sv, h->n_cus) +
                                            ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? (uint64_t)bvh_spheres_tile_list_bytes(per_sample64) : 0) : 0) +
-                               (kernel == RTX_KERNEL_WAVEFRONT ? (uint64_t)wavefront_state_bytes(0, 1) + wavefront_spill_bytes(h->sv, h->n_cus) : 0) +
+                               (kernel == RTX_KERNEL_WAVEFRONT ? (uint64_t)wavefront_state_bytes(0, 1) + wavefront_spill_bytes(h->sv, h->n_cus) +
+                                                                     ((h->sv.bvh_flags & 4u) != 0u && tiled && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u
+                                                                          ? (uint64_t)wavefront_tile_list_bytes(per_sample64) : 0) : 0) +
                                (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY ? (uint64_t)mixed_state_bytes(h->n_cus) : 0);
         const uint64_t room = cap_bytes > fixed ? cap_bytes - fixed : 0;
         const uint64_t fit = room / (per_sample64 * per_ray);
@@ -945,6 +947,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, wavefront_state_bytes(batch * per_sample64, wavefront_levels(h->sv)))) return rc;
+        if (wf_mesh && (h->sv.bvh_flags & 4u) != 0u && tiled && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u)
+            if (int32_t rc = grow(&h->tile_lists, &h->tile_lists_bytes, wavefront_tile_list_bytes(per_sample64))) return rc;
     }
 
     RowsView rv{};
@@ -1096,7 +1100,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
             else
 #endif
                 RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
-                                                     reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream));
+                                                     reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream,
+                                                     (h->sv.bvh_flags & 4u) != 0u && tiled && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? h->tile_lists : nullptr));
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
 #ifdef RTX_LAB

@@ -107,7 +107,9 @@ size_t wavefront_state_bytes(uint64_t n_rays, uint32_t levels);
 uint32_t wavefront_levels(const SceneView &sv);
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
-                                  double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream);
+                                  double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream,
+                                  void *tile_list_mem = nullptr);      // wavefront_tile_list_bytes(rays per sample) bytes, or null: every tile walks
+size_t wavefront_tile_list_bytes(uint64_t rays_per_sample);
 
 #ifdef RTX_LAB       // librtx_hip_lab.so only
 // RTX_KERNEL_WAVEFRONT for trees that hold spheres only (rtx_wavefront_spheres.hip): walk / shade kernels per bounce level,

@@ -218,6 +218,207 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
 // collected for SOME visiting order -- every candidate that can still be the winner (t_lo <= its best_up) -- and the
 // exact tests decide as always.  Pure (x, y)-footprint trees; the 96-byte footprint nodes (at a uniform address the two
 // extra requests are free and the rectangles need no decoding).
+// ------------------------------------------------------------------------------------------------------------------------------
+// Tile lists for level 0 of a pure (x, y)-footprint tree (the sphere packets' idea, rtx_bvh_spheres.hip, with the test a mesh needs).
+// Every ray of an 8x8 tile starts in O = cam_pos + [0, non_focal_offset]^3 and goes through T = hull of the tile's focal points +
+// [0, focal_offset]^3.  Which filter records can such a ray pass?  NOT "the triangles the beam touches": Triangle::distance places its
+// hit point at |n.(v0 - p) / n.d| along the ray (triangle.rs:108-127), so a triangle behind the origin can report a phantom hit in
+// front, and the footprint filter (tri_filter_sign, rtx_device.h) is the only geometry there is:
+//     e_x = (p_x - c_x) |n.d| + d_x |n.(v0 - p)|,    candidate <=> |e_x| <= h_x |n.d| + A     (and the same in y).
+// One thread per tile walks the footprint tree with the beam's (x, y) slabs (an interval origin and an interval direction: linear
+// inequalities in the ray parameter, as build_tile_lists_kernel) and evaluates those two inequalities for each record it reaches in
+// INTERVAL arithmetic over p in O and the unit directions d of the beam: a record some ray of the tile can pass has min |e_x| <=
+// h_x max |n.d| + 2 A (twice the filter's own error allowance: whatever the f32 filter passes for a ray of the tile is in the list).
+// C3: ~1500 records lie under a tile's strip, a few dozen survive.  Entry: {record index, a lower bound of |t| over the beam =
+// min |n.(v0 - p)| / max |n.d|}, sorted by that bound; the packet kernel runs its leaf loop over the list and stops when the bound
+// passes every lane's certain hit.  A tile whose list overflows kMeshTileCap, whose beam degenerates or whose walk exceeds the stack
+// keeps the packet walk.
+constexpr uint32_t kMeshTileCap = 512;
+constexpr uint32_t kMeshTileWalk = 0xFFFFFFFFu;
+struct MeshTileLists {
+    uint32_t *count;                 // [tiles]; null: no lists
+    uint2 *entries;                  // [tiles][kMeshTileCap]: {filter record, bits of t_lb}
+    uint32_t tiles_per_sample;
+};
+
+struct Iv { double lo, hi; };
+__device__ __forceinline__ Iv iv_scale(double k, Iv a) { return k >= 0.0 ? Iv{k * a.lo, k * a.hi} : Iv{k * a.hi, k * a.lo}; }
+__device__ __forceinline__ Iv iv_add(Iv a, Iv b) { return Iv{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ Iv iv_abs(Iv a) { return (a.lo <= 0.0 && a.hi >= 0.0) ? Iv{0.0, fmax(-a.lo, a.hi)} : (a.lo > 0.0 ? a : Iv{-a.hi, -a.lo}); }
+__device__ __forceinline__ Iv iv_mul(Iv a, Iv b)
+{
+    const double p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    return Iv{fmin(fmin(p0, p1), fmin(p2, p3)), fmax(fmax(p0, p1), fmax(p2, p3))};
+}
+__device__ __forceinline__ Iv iv_widen(Iv a) { const double w = (fabs(a.lo) + fabs(a.hi)) * 1e-12 + 1e-300; return Iv{a.lo - w, a.hi + w}; }
+
+constexpr uint32_t kMeshTileStack = 512;                     // the builder's node stack per wave (LDS)
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// One WAVE per tile: lane j computes pixel j's focal point; the walk takes up to 16 nodes off the wave's stack per step, lane l
+// tests child l & 3 of node l >> 2 against the beam's (x, y) slabs; a lane whose child is a leaf the beam can enter tests that
+// leaf's records itself.  The filter's inequalities are evaluated at the 8 corners of the direction box D = T - O (for a fixed
+// origin and fixed signs of n.D and n.(v0 - p) they are affine in each component of D, so their extremes over the box sit at its
+// corners) with the origin as an interval: the dependency between a hit point and the direction that leads to it survives, which
+// plain interval arithmetic over D loses (a record 100 units away would be accepted +- 2 units around its true footprint).
+__global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
+                                                                    const float4 *__restrict__ nodes, const float4 *__restrict__ tri_f32,
+                                                                    MeshTileLists tl, uint32_t n_tiles, uint32_t root)
+{
+    __shared__ uint32_t s_stack[4][kMeshTileStack];
+    __shared__ uint32_t s_idx[4][kMeshTileCap];
+    __shared__ float s_tlb[4][kMeshTileCap];
+    __shared__ uint32_t s_cnt[4];
+    const SceneView &sv = *svp;
+    const RowsView &rv = *rvp;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + wv;
+    if (tile >= n_tiles) return;                            // (wave-uniform)
+    const double nfo = sv.non_focal_offset, fo = sv.focal_offset;
+    const double cam[3] = { sv.cam_pos.x, sv.cam_pos.y, sv.cam_pos.z };
+    double omin[3], omax[3], tmin[3], tmax[3];
+    uint32_t pl, smp;
+    const bool have = ray_index_to_pixel_tiled(rv, (uint64_t)tile * 64u + lane, pl, smp);
+    V3 f = mk(0., 0., 0.);
+    if (have) f = primary_focal_point(sv, rv, pl);
+    const double fp[3] = { f.x, f.y, f.z };
+    for (int a = 0; a < 3; ++a) {
+        omin[a] = cam[a] + fmin(0.0, nfo); omax[a] = cam[a] + fmax(0.0, nfo);
+        tmin[a] = wave_min_f64(have ? fp[a] + fmin(0.0, fo) : __builtin_inf());
+        tmax[a] = wave_max_f64(have ? fp[a] + fmax(0.0, fo) : -__builtin_inf());
+    }
+    if (__ballot(have) == 0ull) { if (lane == 0) tl.count[tile] = 0u; return; }
+    double dlo[3], dhi[3], gap2 = 0.0, far2 = 0.0;
+    bool ok = (root & kBvhFlatNode) != 0u;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = tmin[a] - omax[a], hi = tmax[a] - omin[a];
+        const double w = (fabs(lo) + fabs(hi)) * 1e-12 + 1e-300;
+        dlo[a] = lo - w; dhi[a] = hi + w;
+        const double g = fmax(0.0, fmax(tmin[a] - omax[a], omin[a] - tmax[a]));
+        gap2 += g * g;
+        const double m = fmax(fabs(dlo[a]), fabs(dhi[a]));
+        far2 += m * m;
+        ok = ok && isfinite(dlo[a]) && isfinite(dhi[a]) && isfinite(omin[a]) && isfinite(omax[a]);
+    }
+    const double lmin = sqrt(gap2) * (1.0 - 1e-9), lmax = sqrt(far2) * (1.0 + 1e-9);
+    ok = ok && lmin > 0.0 && isfinite(lmax);
+    Iv pr[3];                                              // the origin relative to the filter's centre
+    double S = sv.tri_extent + 1.0;
+    for (int a = 0; a < 3; ++a) {
+        pr[a] = iv_widen(Iv{omin[a] - sv.sphere_center[a], omax[a] - sv.sphere_center[a]});
+        S += fmax(fabs(pr[a].lo), fabs(pr[a].hi));
+    }
+    ok = ok && S < 1.0e14;
+    // the filter's allowance A = 64 u S for a UNIT direction; the inequalities below are written in D = t - o (both sides scale with |D|)
+    const double A2 = 2.0 * S * (64.0 / 16777216.0) * (1.0 + 1e-6) * lmax;
+
+    uint32_t *const stk = &s_stack[wv][0];
+    if (lane == 0) { s_cnt[wv] = 0u; stk[0] = root & ~kBvhFlatNode; }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t sp = 1;
+    ok = __ballot(!ok) == 0ull;
+    while (ok && sp != 0u) {
+        const uint32_t take = sp < 16u ? sp : 16u;
+        const uint32_t slot = lane >> 2, c = lane & 3u;
+        const bool active = slot < take;
+        const uint32_t node = active ? stk[sp - 1u - slot] : 0u;
+        sp -= take;
+        __builtin_amdgcn_wave_barrier();
+        bool bad = false, interior = false, leaf = false;
+        uint32_t link = 0, cnt = 0xFFFFFFFFu;
+        if (active) {
+            const float4 *np = nodes + 8 * (size_t)node;
+            const float4 r = np[c];                        // {lo.x, lo.y, hi.x, hi.y}
+            link = reinterpret_cast<const uint32_t *>(np + 4)[c];
+            cnt = reinterpret_cast<const uint32_t *>(np + 5)[c];
+            if (cnt != 0xFFFFFFFFu) {
+                const double lo[2] = { (double)r.x, (double)r.y }, hi[2] = { (double)r.z, (double)r.w };
+                double u0 = 0.0, u1 = __builtin_inf();
+                bool miss = false;
+                for (int k = 0; k < 2; ++k) {
+                    if (dlo[k] > 0.0) u1 = fmin(u1, (hi[k] - omin[k]) / dlo[k]);
+                    else if (dlo[k] < 0.0) u0 = fmax(u0, (hi[k] - omin[k]) / dlo[k]);
+                    else if (omin[k] > hi[k]) miss = true;
+                    if (dhi[k] > 0.0) u0 = fmax(u0, (lo[k] - omax[k]) / dhi[k]);
+                    else if (dhi[k] < 0.0) u1 = fmin(u1, (lo[k] - omax[k]) / dhi[k]);
+                    else if (omax[k] < lo[k]) miss = true;
+                }
+                if (!(u0 == u0) || !(u1 == u1)) bad = true;
+                else if (!(miss || u0 * (1.0 - 1e-9) > u1 * (1.0 + 1e-9) + 1e-300)) {
+                    interior = cnt == 0u;
+                    leaf = cnt != 0u;
+                    if (leaf && (cnt & kBvhTriLeaf) == 0u) bad = true;       // (a pure footprint tree holds triangle leaves only)
+                }
+            }
+        }
+        // the interior children the beam enters go back to the stack
+        const unsigned long long im = __ballot(interior);
+        const uint32_t pos = sp + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+        if (interior) { if (pos < kMeshTileStack) stk[pos] = link & ~kBvhFlatNode; else bad = true; }
+        sp += (uint32_t)__builtin_popcountll(im);
+        // a lane with a leaf tests its records
+        if (leaf && !bad) {
+            const uint32_t first = link, m = cnt & 0xFFFFu;
+            for (uint32_t j = 0; j < m; ++j) {
+                const float4 A = tri_f32[2 * (size_t)(first + j)], B = tri_f32[2 * (size_t)(first + j) + 1];
+                Iv nv = iv_add(iv_add(iv_scale(-(double)A.x, pr[0]), iv_scale(-(double)A.y, pr[1])), iv_scale(-(double)A.z, pr[2]));
+                nv.lo += (double)A.w; nv.hi += (double)A.w;
+                const Iv anv = iv_abs(iv_widen(nv));
+                const Iv axv = Iv{pr[0].lo - (double)B.x, pr[0].hi - (double)B.x}, ayv = Iv{pr[1].lo - (double)B.y, pr[1].hi - (double)B.y};
+                double m1x = __builtin_inf(), m2x = -__builtin_inf(), m1y = __builtin_inf(), m2y = -__builtin_inf();
+                double nd_min = __builtin_inf(), nd_max = -__builtin_inf(), and_max = 0.0;
+                for (int v = 0; v < 8; ++v) {
+                    const double Dx = (v & 1) ? dhi[0] : dlo[0], Dy = (v & 2) ? dhi[1] : dlo[1], Dz = (v & 4) ? dhi[2] : dlo[2];
+                    const double nD = (double)A.x * Dx + (double)A.y * Dy + (double)A.z * Dz;
+                    const double a = fabs(nD) * (1.0 + 1e-12);
+                    nd_min = fmin(nd_min, nD); nd_max = fmax(nd_max, nD); and_max = fmax(and_max, a);
+                    const Iv ex = iv_add(iv_scale(a, axv), iv_scale(Dx, anv)), ey = iv_add(iv_scale(a, ayv), iv_scale(Dy, anv));
+                    const double Rx = ((double)B.z * a + A2) * (1.0 + 1e-9), Ry = ((double)B.w * a + A2) * (1.0 + 1e-9);
+                    m1x = fmin(m1x, ex.lo - Rx); m2x = fmax(m2x, ex.hi + Rx);
+                    m1y = fmin(m1y, ey.lo - Ry); m2y = fmax(m2y, ey.hi + Ry);
+                }
+                if (!(m1x == m1x) || !(m2x == m2x) || !(m1y == m1y) || !(m2y == m2y)) { bad = true; break; }
+                if (and_max == 0.0) continue;             // n.D = 0 at every corner: no ray of the tile has a finite distance
+                const bool mixed = nd_min < 0.0 && nd_max > 0.0;            // n.D changes sign inside the box: not affine there -- a candidate
+                const bool pass = mixed || (m1x <= 0.0 && m2x >= 0.0 && m1y <= 0.0 && m2y >= 0.0);
+                if (!pass) continue;
+                const float t_lb = round_down_f32_dev(anv.lo * lmin / and_max * (1.0 - 1e-6));
+                const uint32_t k = atomicAdd(&s_cnt[wv], 1u);
+                if (k < kMeshTileCap) { s_idx[wv][k] = first + j; s_tlb[wv][k] = t_lb; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        ok = __ballot(bad) == 0ull && s_cnt[wv] <= kMeshTileCap;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = s_cnt[wv];
+    if (!ok || n > kMeshTileCap) { if (lane == 0) tl.count[tile] = kMeshTileWalk; return; }
+    // rank sort by t_lb (ties: the order of arrival) into the tile's list
+    uint2 *const out = tl.entries + (size_t)tile * kMeshTileCap;
+    for (uint32_t e = lane; e < n; e += 64u) {
+        const float te = s_tlb[wv][e];
+        uint32_t rank = 0;
+        for (uint32_t g = 0; g < n; ++g) {
+            const float tg = s_tlb[wv][g];
+            rank += (tg < te || (tg == te && g < e)) ? 1u : 0u;
+        }
+        out[rank] = make_uint2(s_idx[wv][e], __float_as_uint(te));
+    }
+    if (lane == 0) tl.count[tile] = n;
+}
+
 constexpr int kPkStack = 128;                                      // wave-uniform stack entries (the host checks 3 * depth + 2 against it)
 #ifndef RTX_PK_WAVES
 #define RTX_PK_WAVES 7
@@ -246,13 +447,43 @@ constexpr int kPkLaneStack = 63;
 #define RTX_PK_BALLOT(x) __builtin_amdgcn_ballot_w64(x)          // the mask straight out of v_cmp (HIP's __ballot re-materialises the bool: 2 more VALU)
 #endif
 
+// One filter record of a triangle leaf against the wave's rays (uniform address: scalar loads): the lanes that are IN filter it,
+// bound it (tri_bounds) and queue it as a candidate; used by the walk's leaf loop and by the sweep over a tile's list.
+#define RTX_PK_TRI_RECORD(IDX, IN)                                                                                                  \
+                {                                                                                                                   \
+                    const uint32_t rec_ = (IDX);                                                                                    \
+                    const PkConst4 rp = ctri + 2 * (size_t)rec_;                                                                    \
+                    const float4 A = rp[0], B = rp[1];                                                                              \
+                    const bool pass = (IN) && (int)tri_filter_sign(A, B, tp) >= 0;                                                  \
+                    if (RTX_PK_BALLOT(pass) != 0ull) {                                                                              \
+                        const PkConst4 gp = cgeo + 2 * (size_t)rec_;                                                                \
+                        const float4 g0 = gp[0], g1 = gp[1];                                                                        \
+                        if (pass) {                                                                                                 \
+                            float thi;                                                                                              \
+                            const float tlo = tri_bounds(A, g0, g1, tp, thi);                                                       \
+                            if (tlo <= best_up && tlo < __builtin_inff()) {                                                         \
+                                best_up = fminf(best_up, thi);                                                                      \
+                                if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {       /* more live candidates than the queue holds: */ \
+                                    if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;   /* to the overflow list */ \
+                                    else { overflow = true; best_up = -__builtin_inff(); }     /* (full: the shade kernel tests every shape for this ray) */ \
+                                }                                                                                                   \
+                                if (!overflow) {                                                                                    \
+                                    lq[(size_t)qcnt * kBvhThreads + tid] = rec_ | kQueueTri;                                        \
+                                    lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);                     \
+                                    qcnt += 1;                                                                                      \
+                                }                                                                                                   \
+                            }                                                                                                       \
+                        }                                                                                                           \
+                    }                                                                                                               \
+                }
+
 // PLAIN 1: every node is a footprint node, every leaf a triangle leaf (C3, C5).  PLAIN 0: a joint tree -- 3-D nodes over
 // sphere boxes and the footprints of the other planes, the (x, y) footprint sub-tree behind links with kBvhFlatNode, sphere
 // leaves with bvh_traverse_spheres' bounds (cmax_ru: SceneView::sphere_cmax rounded up, for their error terms).
 template <int PLAIN>
 __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void wf_trace_packet_kernel(const WfState st, Counters *__restrict__ ctr,
                                                                                 const float4 *__restrict__ nodes, const MeshArrays ma,
-                                                                                uint32_t root, float cmax_ru, uint32_t lane_stack)
+                                                                                uint32_t root, float cmax_ru, uint32_t lane_stack, const MeshTileLists tl)
 {
     __shared__ uint32_t pk_stack[kBvhThreads >> 6][kPkStack];
     __shared__ uint32_t lds_q[2 * kMeshQueue][kBvhThreads];
@@ -312,6 +543,25 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
             }
         }
 
+        // a pure footprint tree: the tile's list, if it has one (wave-uniform: scalar loads), instead of the walk
+        if constexpr (PLAIN != 0) {
+            if (tl.count != nullptr && node != kNone) {
+                const uint32_t tile_of = (uint32_t)((t_next - 1ull) % (unsigned long long)tl.tiles_per_sample);
+                const uint32_t list_n = pk_const(tl.count)[tile_of];
+                if (list_n != kMeshTileWalk) {
+                    const PkConstU32 ent = pk_const(reinterpret_cast<const uint32_t *>(tl.entries + (size_t)tile_of * kMeshTileCap));
+                    for (uint32_t k = 0; k < list_n; ++k) {
+                        const uint32_t e = ent[2 * k];
+                        const float t_lb = __uint_as_float(ent[2 * k + 1]);
+                        const bool in = walk && t_lb <= best_up;
+                        if (RTX_PK_BALLOT(in) == 0ull) break;      // sorted by t_lb: nothing further can beat any lane's certain hit
+                        if (in) nleaf += 1;
+                        RTX_PK_TRI_RECORD(e, in)
+                    }
+                    node = kNone;
+                }
+            }
+        }
         int stk_v = 0;                                              // the lane-stack form of the wave's stack
         while (node != kNone) {
             // the node's bytes at a wave-uniform address.  A footprint node: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
@@ -381,30 +631,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
                     }
                     continue;
                 }
-                for (uint32_t j = 0; j < n; ++j) {
-                    const PkConst4 rp = ctri + 2 * (size_t)(first + j);
-                    const float4 A = rp[0], B = rp[1];
-                    const bool pass = in && (int)tri_filter_sign(A, B, tp) >= 0;
-                    if (RTX_PK_BALLOT(pass) == 0ull) continue;
-                    const PkConst4 gp = cgeo + 2 * (size_t)(first + j);
-                    const float4 g0 = gp[0], g1 = gp[1];
-                    if (pass) {
-                        float thi;
-                        const float tlo = tri_bounds(A, g0, g1, tp, thi);
-                        if (tlo <= best_up && tlo < __builtin_inff()) {
-                            best_up = fminf(best_up, thi);
-                            if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {       // more live candidates than the queue holds:
-                                if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;   // to the overflow list
-                                else { overflow = true; best_up = -__builtin_inff(); }     // (full: the shade kernel tests every shape for this ray)
-                            }
-                            if (!overflow) {
-                                lq[(size_t)qcnt * kBvhThreads + tid] = (first + j) | kQueueTri;
-                                lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
-                                qcnt += 1;
-                            }
-                        }
-                    }
-                }
+                for (uint32_t j = 0; j < n; ++j) RTX_PK_TRI_RECORD(first + j, in)
             }
             // interior children any lane entered, nearest first (wave-uniform integer keys: scalar code); the farther ones go
             // to the wave's stack.  None or one entered (most visits below the top levels): nothing to order, nothing to push --
@@ -899,8 +1126,15 @@ size_t wavefront_spill_bytes(const SceneView &sv, int n_cus)
     return std::max(own, bvh_mesh_spill_bytes(sv, n_cus));
 }
 
+size_t wavefront_tile_list_bytes(uint64_t rays_per_sample)
+{
+    const uint64_t n_tiles = rays_per_sample >> 6;
+    return (size_t)(((n_tiles * sizeof(uint32_t) + 255) & ~(uint64_t)255) + n_tiles * kMeshTileCap * sizeof(uint2));
+}
+
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
-                                  double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream)
+                                  double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream,
+                                  void *tile_list_mem)
 {
     if (rv.n_rays == 0) return hipSuccess;
     const uint32_t levels = wavefront_levels(sv);
@@ -946,7 +1180,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
     const bool hybrid = true;
     const bool packets = rv.tiles_x != 0u && 3u * sv.bvh_depth + 2u <= (uint32_t)kPkStack;
     if (!packets) return hipErrorInvalidValue;               // (wavefront_mesh_supported() keeps the caller from asking)
-    (void)d_sv; (void)qnodes; (void)deep;
+    (void)qnodes; (void)deep;
 #endif
     const float cmax_ru = std::nextafterf((float)sv.sphere_cmax, INFINITY);
     const uint32_t packet_blocks = (uint32_t)std::min<uint64_t>((n + kBvhThreads - 1) / kBvhThreads, (uint64_t)n_cus * (joint ? kPkWavesJoint : kPkWaves));
@@ -963,8 +1197,18 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
 #endif
         if (level == 0u && packets) {
             const uint32_t lane_stack = 3u * sv.bvh_depth + 2u <= (uint32_t)kPkLaneStack && (sv.tuning & RTX_TUNE_PK_LDS_STACK) == 0u ? 1u : 0u;
-            if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
-            else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack);
+            MeshTileLists tl{};
+            if (!joint && tile_list_mem && (sv.tuning & RTX_TUNE_NO_TILE_LISTS) == 0u && rv.n_samples != 0u) {
+                // what each tile's primary rays can pass the filter of, once per tile (build_mesh_tile_lists_kernel)
+                const uint32_t n_tiles = (uint32_t)((rv.n_rays / rv.n_samples) >> 6);
+                tl.count = reinterpret_cast<uint32_t *>(tile_list_mem);
+                tl.entries = reinterpret_cast<uint2 *>(static_cast<char *>(tile_list_mem) + (((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255));
+                tl.tiles_per_sample = n_tiles;
+                hipLaunchKernelGGL(build_mesh_tile_lists_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream, d_sv, d_rv, nodes, ma.tri_f32, tl,
+                                   n_tiles, sv.bvh_root);
+            }
+            if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack, tl);
+            else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack, tl);
         }
 #ifdef RTX_LAB
         else if (qn) {

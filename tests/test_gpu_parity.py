@@ -907,6 +907,62 @@ def test_tile_lists_of_the_primary_rays_keep_the_bits(gpu, oracle):
     hnd.close()
 
 
+def test_tile_lists_of_a_mesh_keep_the_bits(gpu):
+    """Level 0 of a pure (x, y)-footprint tree (RTX_KERNEL_WAVEFRONT's packets): which filter records a tile's primary rays can pass
+    is found once per tile (build_mesh_tile_lists_kernel: the footprint tree walked with the beam's (x, y) slabs, tri_filter_sign's
+    inequalities at the corners of the direction box) and every packet of the tile runs its leaf code over that list.  Same image and
+    segment count as the packets' own walks (RTX_TUNE_NO_TILE_LISTS) and as the exhaustive kernel -- in particular where
+    Triangle::distance's |t| matters: the camera INSIDE the mesh (triangles behind the origin report phantom hits in front,
+    triangle.rs:108-127), looking along each axis and down the footprints' unbounded axis, far outside, with a dense mesh whose
+    lists overflow, partial tiles, a band of blocks, and lens settings that degenerate the beam."""
+    import torch
+    from rust_raytracing_amd import scenes
+    mesh = scenes.light_every(scenes.random_triangles(60000, 2), 7)
+    dense = scenes.light_every(scenes.compact(scenes.random_triangles(60000, 3), k=0.12, x0=6.0), 7)       # ~1000 records behind a tile
+    cases = [("c3 recipe", mesh, 384, 216, scenes.CAMERA, {}), ("partial tiles", mesh, 381, 211, scenes.CAMERA, {}),
+             ("inside", mesh, 256, 144, ((60.0, 3.0, -2.0), (0.7, 0.6, 0.2), 1.3), {}),
+             ("inside, along -x", mesh, 256, 144, ((60.0, 0.0, 0.0), (-1.0, 0.0, 0.0), 1.2), {}),
+             ("inside, along +y", mesh, 256, 144, ((60.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1.2), {}),
+             ("inside, down z", mesh, 256, 144, ((60.0, 0.0, 30.0), (0.0, 0.0, -1.0), 1.2), {}),
+             ("behind the mesh, looking away", mesh, 256, 144, ((130.0, 5.0, 5.0), (1.0, 0.1, 0.0), 1.0), {}),
+             ("far outside", mesh, 256, 144, ((-3.0e6, 10.0, 5.0), (1.0, 0.0, 0.0), 0.0003), {}),
+             ("dense", dense, 256, 144, scenes.CAMERA, {}),
+             ("focal length 0", mesh, 256, 144, scenes.CAMERA, dict(focal_length=0.0)),
+             ("focal length < 0", mesh, 256, 144, scenes.CAMERA, dict(focal_length=-4.0)),
+             ("pinhole", mesh, 256, 144, scenes.CAMERA, dict(focal_offset=0.0, non_focal_offset=0.0)),
+             ("negative offsets", mesh, 256, 144, scenes.CAMERA, dict(focal_offset=-0.3, non_focal_offset=-0.2)),
+             ("wide aperture", mesh, 256, 144, scenes.CAMERA, dict(non_focal_offset=5.0, focal_length=30.0))]
+    used = 0
+    for name, objs, w, h, cam, lens in cases:
+        out = {}
+        for tag, kern, tune in (("lists", gpu.RTX_KERNEL_WAVEFRONT, 0), ("walks", gpu.RTX_KERNEL_WAVEFRONT, gpu.RTX_TUNE_NO_TILE_LISTS),
+                                ("exact", gpu.RTX_KERNEL_EXACT, 0)):
+            hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=2, seed=11, tuning=tune, **lens).upload(0)
+            buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+            st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+            hnd.close()
+            out[tag] = (buf.cpu().numpy(), st)
+        a, sa = out["lists"]
+        assert sa.kernel == gpu.RTX_KERNEL_WAVEFRONT, name
+        for other in ("walks", "exact"):
+            b, sb = out[other]
+            assert np.array_equal(a, b, equal_nan=True) and sa.segments == sb.segments, (name, other)
+        assert sa.box_tests <= out["walks"][1].box_tests, name
+        used += sa.box_tests < 0.8 * out["walks"][1].box_tests
+    assert used >= 6
+    # a band of blocks
+    hnd = hip_scene(gpu, mesh, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_WAVEFRONT, rays_per_pixel=2, seed=11).upload(0)
+    w, h = 384, 216
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    hnd.render_rows(w, h, 0, 1, h, full.data_ptr())
+    n = int(gpu.abi.load_library(False).rtx_blocks_row_count(h, 8, 5, 8))
+    band = torch.zeros((n, w, 3), dtype=torch.float64, device="cuda:0")
+    hnd.render_blocks(w, h, 8, 5, 8, band.data_ptr())
+    rows = np.concatenate([np.arange(r, min(r + 8, h)) for r in range(5 * 8, h, 8 * 8)])
+    assert np.array_equal(band.cpu().numpy(), full.cpu().numpy()[rows])
+    hnd.close()
+
+
 def test_product_fallback_for_a_sphere_tree_without_64_byte_nodes(gpu):
     """The product library holds the sphere kernels in their 64-byte-node instances only.  A sphere tree whose nodes have no such
     form (coordinates beyond the quantisation's exact range: |origin / step| + 256 >= 2^24) renders with the LDS sweep under every
