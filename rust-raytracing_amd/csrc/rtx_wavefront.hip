@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
     __shared__ uint32_t s_idx[4][kMeshTileCap];
     __shared__ float s_tlb[4][kMeshTileCap];
     __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_lstart[4][64], s_lfirst[4][64];
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -368,14 +369,56 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
         const uint32_t pos = sp + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
         if (interior) { if (pos < kMeshTileStack) stk[pos] = link & ~kBvhFlatNode; else bad = true; }
         sp += (uint32_t)__builtin_popcountll(im);
-        // a lane with a leaf tests its records
-        if (leaf && !bad) {
-            const uint32_t first = link, m = cnt & 0xFFFFu;
-            for (uint32_t j = 0; j < m; ++j) {
-                const float4 A = tri_f32[2 * (size_t)(first + j)], B = tri_f32[2 * (size_t)(first + j) + 1];
+        // the records of the leaves the beam enters, flattened across the lanes (a leaf holds up to 6: one lane per RECORD, not per
+        // leaf -- the loads of a step's ~100 records are in flight together instead of five deep)
+        {
+            const bool lf = leaf && !bad;
+            const uint32_t m = lf ? (cnt & 0xFFFFu) : 0u;
+            uint32_t incl = m;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+                if ((int)lane >= off) incl += t;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            s_lstart[wv][lane] = incl - m;
+            s_lfirst[wv][lane] = link;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t r = lane; r < total; r += 64u) {
+                uint32_t L = 0;                                   // the last lane whose first record is <= r (binary search: starts ascend)
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (s_lstart[wv][L + step] <= r) L += step;
+                const uint32_t rec = s_lfirst[wv][L] + (r - s_lstart[wv][L]);
+                const float4 A = tri_f32[2 * (size_t)rec], B = tri_f32[2 * (size_t)rec + 1];
                 Iv nv = iv_add(iv_add(iv_scale(-(double)A.x, pr[0]), iv_scale(-(double)A.y, pr[1])), iv_scale(-(double)A.z, pr[2]));
                 nv.lo += (double)A.w; nv.hi += (double)A.w;
                 const Iv anv = iv_abs(iv_widen(nv));
+                // a cheap necessary condition first (most records under the strip fail it: their plane is elsewhere in z): the hit point
+                // q = p + u D has its (x, y) in the record's rectangle only for u in [u0, u1] (the slab test again, on the rectangle, in
+                // the filter's coordinates and with its allowance), and |n.(v0 - p)| = u |n.D| there -- in plain interval arithmetic
+                {
+                    const double pad = A2 / lmin + 1e-9 * S;                                   // (the allowance as a length, generously)
+                    double u0 = 0.0, u1 = __builtin_inf();
+                    bool miss = false;
+                    for (int k = 0; k < 2; ++k) {
+                        const double rlo = (double)(k == 0 ? B.x : B.y) - (double)(k == 0 ? B.z : B.w) - pad;
+                        const double rhi = (double)(k == 0 ? B.x : B.y) + (double)(k == 0 ? B.z : B.w) + pad;
+                        if (dlo[k] > 0.0) u1 = fmin(u1, (rhi - pr[k].lo) / dlo[k]);
+                        else if (dlo[k] < 0.0) u0 = fmax(u0, (rhi - pr[k].lo) / dlo[k]);
+                        else if (pr[k].lo > rhi) miss = true;
+                        if (dhi[k] > 0.0) u0 = fmax(u0, (rlo - pr[k].hi) / dhi[k]);
+                        else if (dhi[k] < 0.0) u1 = fmin(u1, (rlo - pr[k].hi) / dhi[k]);
+                        else if (pr[k].hi < rlo) miss = true;
+                    }
+                    if (u0 == u0 && u1 == u1) {                                                // (NaN: no shortcut, the corners decide)
+                        if (miss || u0 * (1.0 - 1e-9) > u1 * (1.0 + 1e-9) + 1e-300) continue;
+                        const Iv nDb = iv_abs(iv_widen(iv_add(iv_add(iv_scale((double)A.x, Iv{dlo[0], dhi[0]}), iv_scale((double)A.y, Iv{dlo[1], dhi[1]})),
+                                                              iv_scale((double)A.z, Iv{dlo[2], dhi[2]}))));
+                        const double slack = 1e-9 * (anv.hi + nDb.hi * (u1 < 1e300 ? u1 : 0.0)) + A2 * 4.0;
+                        if (anv.lo > nDb.hi * u1 + slack || anv.hi + slack < nDb.lo * u0) continue;
+                    }
+                }
                 const Iv axv = Iv{pr[0].lo - (double)B.x, pr[0].hi - (double)B.x}, ayv = Iv{pr[1].lo - (double)B.y, pr[1].hi - (double)B.y};
                 double m1x = __builtin_inf(), m2x = -__builtin_inf(), m1y = __builtin_inf(), m2y = -__builtin_inf();
                 double nd_min = __builtin_inf(), nd_max = -__builtin_inf(), and_max = 0.0;
@@ -389,15 +432,16 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
                     m1x = fmin(m1x, ex.lo - Rx); m2x = fmax(m2x, ex.hi + Rx);
                     m1y = fmin(m1y, ey.lo - Ry); m2y = fmax(m2y, ey.hi + Ry);
                 }
-                if (!(m1x == m1x) || !(m2x == m2x) || !(m1y == m1y) || !(m2y == m2y)) { bad = true; break; }
+                if (!(m1x == m1x) || !(m2x == m2x) || !(m1y == m1y) || !(m2y == m2y)) { bad = true; continue; }
                 if (and_max == 0.0) continue;             // n.D = 0 at every corner: no ray of the tile has a finite distance
                 const bool mixed = nd_min < 0.0 && nd_max > 0.0;            // n.D changes sign inside the box: not affine there -- a candidate
                 const bool pass = mixed || (m1x <= 0.0 && m2x >= 0.0 && m1y <= 0.0 && m2y >= 0.0);
                 if (!pass) continue;
                 const float t_lb = round_down_f32_dev(anv.lo * lmin / and_max * (1.0 - 1e-6));
                 const uint32_t k = atomicAdd(&s_cnt[wv], 1u);
-                if (k < kMeshTileCap) { s_idx[wv][k] = first + j; s_tlb[wv][k] = t_lb; }
+                if (k < kMeshTileCap) { s_idx[wv][k] = rec; s_tlb[wv][k] = t_lb; }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
         ok = __ballot(bad) == 0ull && s_cnt[wv] <= kMeshTileCap;
