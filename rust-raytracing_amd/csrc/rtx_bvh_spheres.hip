@@ -711,15 +711,21 @@ __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kerne
     unsigned long long out_next = 0, out_end = 0;                       // its reserved slots of the survivors' queue
     unsigned long long segs = 0, box_tests = 0, leaf_filters = 0, exact = 0;
 
+    // a packet over its tile's list is ~10 us of work, so the grabs are twice the launch's size for them (the host sizes rv.grab for
+    // stage 2's longer segments): rank 0's band of the C2 frame at N = 8: stage 1 1.83 -> 1.44 ms (x4: 1.42, x8: 1.52); the full frame: level
+#ifndef RTX_SPK_GRAB_MUL
+#define RTX_SPK_GRAB_MUL 2
+#endif
+    const unsigned long long pk_grab = (unsigned long long)rv.grab * RTX_SPK_GRAB_MUL;
     for (;;) {
         if (wave_next >= wave_end) {
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(work_counter, (unsigned long long)rv.grab);     // (rv.grab is a multiple of 64)
+            if (lane == 0) base = atomicAdd(work_counter, pk_grab);     // (a multiple of 64)
             base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
                    __builtin_amdgcn_readfirstlane((uint32_t)base);
             if (base >= n_rays) break;
             wave_next = base;
-            wave_end = base + rv.grab < n_rays ? base + rv.grab : n_rays;
+            wave_end = base + pk_grab < n_rays ? base + pk_grab : n_rays;
         }
         const unsigned long long my = wave_next + lane;
         wave_next += 64ull;
