@@ -206,6 +206,13 @@ def useful_ops(kernel, tri, box, leaf, exact, filt=0.0):
     return exact * LANE_OPS["tri_exact" if tri else "sphere_exact"], exact * (112.0 if tri else 32.0)
 
 
+# The work round 3's algorithm did per ray segment (lane-instructions of the tests it counted: profiles/r03_bench_n1.json, roofline.
+# algorithmic.lane_ops_per_segment).  roofline.frac counts the tests a kernel PERFORMS, so it falls when a kernel stops doing tests it does
+# not need (round 4's tile lists: 131 box tests per primary ray -> none); frac_r03_work = segments x THIS fixed figure / time / peak is the
+# same quantity against a fixed amount of work per unit, comparable across rounds.
+R03_LANE_OPS_PER_SEGMENT = 2124.098          # C2 / C4 (the 10k-sphere scene)
+
+
 def algorithmic(acc, cfg):
     """What the kernel counted in this run, priced in lane-instructions and bytes (unit = one ray segment)."""
     steps = max(acc.n, 1)
@@ -225,6 +232,9 @@ def algorithmic(acc, cfg):
         exact = acc.exact / steps
         ops, nbytes = useful_ops(acc.kernel, tri, 0.0, 0.0, exact)
     avg_ms = acc.trace_ms / steps
+    fixed = R03_LANE_OPS_PER_SEGMENT if (cfg.get("scene") == "spheres" and cfg.get("n") == 10000 and acc.kernel == 4) else None
+    if fixed and avg_ms > 0:
+        out["frac_r03_work"] = fixed * seg / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS
     out.update({"lane_ops_per_step": ops, "bytes_per_step": nbytes, "bytes_per_segment": nbytes / seg if seg else 0.0,
                 "lane_ops_per_segment": ops / seg if seg else 0.0,
                 "Tlane_ops_per_s": ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
@@ -370,6 +380,7 @@ def compact_line(full, detail_path):
     other legs as rows of numbers (columns named once).  Every value is a rounded copy of one in the full record (`detail`)."""
     r = full["roofline"]
     roof = {"bound": r["bound"], "achieved": _sig(r["achieved"]), "peak": _sig(r["peak"]), "unit": r["unit"], "frac": _sig(r["frac"]),
+            "frac_r03_work": _sig((r.get("algorithmic") or {}).get("frac_r03_work")),
             "traffic": _sig(r["traffic"]) if r.get("traffic") else None,
             "issued_frac": _sig((r.get("issued") or {}).get("frac")), "lane_utilisation": _sig(r.get("lane_utilisation"), 3),
             "valu_busy": _sig(r.get("valu_busy"), 3), "hbm_frac": _sig(r.get("hbm_frac"), 3),
