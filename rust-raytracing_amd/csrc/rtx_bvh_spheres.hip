@@ -54,7 +54,7 @@ struct SphQueue {
 };
 constexpr uint32_t kSphQueueChunk = 512;
 #ifndef RTX_SPH_CUT
-#define RTX_SPH_CUT 16
+#define RTX_SPH_CUT 24
 #endif
 #ifndef RTX_SPH_CUT_DONE
 #define RTX_SPH_CUT_DONE 32
