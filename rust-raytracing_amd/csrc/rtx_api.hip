@@ -811,6 +811,9 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
     const uint32_t per_sample = (uint32_t)per_sample64;
     // samples per launch: all of them unless the sample planes would exceed the scratch cap (or 2^32 rays)
     uint64_t batch = spp;
+    // tile lists for the primary rays (sphere trees: build_tile_lists_kernel; pure footprint trees in the wavefront form:
+    // build_mesh_tile_lists_kernel) -- 2 KB resp. 4 KB per tile, so only where they stay a small part of the scratch cap (decided below)
+    uint64_t tile_list_bytes = 0;
     {
         // bytes per ray of a batch: the 32-byte sample record (+ the wavefront kernels' state, ~270 B)
         // (+ the survivors' queue of the sphere kernel's two-stage form, 64 B)
@@ -829,11 +832,14 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         // what a launch allocates whatever its batch -- the survivors' queue's chunk per resident wave and counters, the
         // wavefront form's level counters and overflow list, the HBM stack columns -- comes off the cap first; the floor is ONE
         // sample per launch (a frame cannot be cut finer), which a limit below that size gets with the overhead on top
-        const uint64_t fixed = (sph2 ? (uint64_t)bvh_spheres_queue_bytes(0, h->n_cus) + bvh_spheres_spill_bytes(h->sv, h->n_cus) +
-                                           ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? (uint64_t)bvh_spheres_tile_list_bytes(per_sample64) : 0) : 0) +
-                               (kernel == RTX_KERNEL_WAVEFRONT ? (uint64_t)wavefront_state_bytes(0, 1) + wavefront_spill_bytes(h->sv, h->n_cus) +
-                                                                     ((h->sv.bvh_flags & 4u) != 0u && tiled && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u
-                                                                          ? (uint64_t)wavefront_tile_list_bytes(per_sample64) : 0) : 0) +
+        if ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u && tiled) {
+            if (sph2) tile_list_bytes = bvh_spheres_tile_list_bytes(per_sample64);
+            else if (kernel == RTX_KERNEL_WAVEFRONT && (h->sv.bvh_flags & 4u) != 0u) tile_list_bytes = wavefront_tile_list_bytes(per_sample64);
+            if (tile_list_bytes > cap_bytes / 4) tile_list_bytes = 0;           // (a frame of ~10^8 pixels: the packets walk)
+        }
+        const uint64_t fixed = tile_list_bytes +
+                               (sph2 ? (uint64_t)bvh_spheres_queue_bytes(0, h->n_cus) + bvh_spheres_spill_bytes(h->sv, h->n_cus) : 0) +
+                               (kernel == RTX_KERNEL_WAVEFRONT ? (uint64_t)wavefront_state_bytes(0, 1) + wavefront_spill_bytes(h->sv, h->n_cus) : 0) +
                                (kernel == RTX_KERNEL_MIXED || kernel == RTX_KERNEL_MIXED_VERIFY ? (uint64_t)mixed_state_bytes(h->n_cus) : 0);
         const uint64_t room = cap_bytes > fixed ? cap_bytes - fixed : 0;
         const uint64_t fit = room / (per_sample64 * per_ray);
@@ -930,8 +936,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
     if (spheres_two_stage) {
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, bvh_spheres_queue_bytes(batch * per_sample64, h->n_cus))) return rc;
-        if ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u)
-            if (int32_t rc = grow(&h->tile_lists, &h->tile_lists_bytes, bvh_spheres_tile_list_bytes(per_sample64))) return rc;
+        if (tile_list_bytes != 0)
+            if (int32_t rc = grow(&h->tile_lists, &h->tile_lists_bytes, (size_t)tile_list_bytes)) return rc;
 #ifdef RTX_LAB
         if (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) {
             const size_t a = bvh_spheres_pool2_bytes(h->n_cus), b = bvh_spheres_pair_bytes(h->n_cus);
@@ -947,8 +953,8 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
         if (int32_t rc = grow((void **)&h->state, &h->state_bytes, need)) return rc;
         if (int32_t rc = grow(&h->wf_state, &h->wf_bytes, wavefront_state_bytes(batch * per_sample64, wavefront_levels(h->sv)))) return rc;
-        if (wf_mesh && (h->sv.bvh_flags & 4u) != 0u && tiled && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u)
-            if (int32_t rc = grow(&h->tile_lists, &h->tile_lists_bytes, wavefront_tile_list_bytes(per_sample64))) return rc;
+        if (wf_mesh && tile_list_bytes != 0)
+            if (int32_t rc = grow(&h->tile_lists, &h->tile_lists_bytes, (size_t)tile_list_bytes)) return rc;
     }
 
     RowsView rv{};
@@ -1101,7 +1107,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
                 RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
                                                      reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream,
-                                                     (h->sv.bvh_flags & 4u) != 0u && tiled && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? h->tile_lists : nullptr));
+                                                     wf_mesh && tile_list_bytes != 0 ? h->tile_lists : nullptr));
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
 #ifdef RTX_LAB
@@ -1129,7 +1135,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
                                                        stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr,
                                                        stage2_slots ? h->slots : nullptr,
-                                                       spheres_two_stage && (tuning & RTX_TUNE_NO_TILE_LISTS) == 0u ? h->tile_lists : nullptr));
+                                                       spheres_two_stage && tile_list_bytes != 0 ? h->tile_lists : nullptr));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,
