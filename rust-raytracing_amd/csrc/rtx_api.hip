@@ -834,7 +834,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
         // sample per launch (a frame cannot be cut finer), which a limit below that size gets with the overhead on top
         if ((tuning & RTX_TUNE_NO_TILE_LISTS) == 0u && tiled) {
             if (sph2) tile_list_bytes = bvh_spheres_tile_list_bytes(per_sample64);
-            else if (kernel == RTX_KERNEL_WAVEFRONT && (h->sv.bvh_flags & 4u) != 0u) tile_list_bytes = wavefront_tile_list_bytes(per_sample64);
+            else if (kernel == RTX_KERNEL_WAVEFRONT && wf_mesh) tile_list_bytes = wavefront_tile_list_bytes(per_sample64);
             if (tile_list_bytes > cap_bytes / 4) tile_list_bytes = 0;           // (a frame of ~10^8 pixels: the packets walk)
         }
         const uint64_t fixed = tile_list_bytes +

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kBvhThreads, kWfTraceWaves) void wf_trace_kernel(co
 // keeps the packet walk.
 constexpr uint32_t kMeshTileCap = 512;
 constexpr uint32_t kMeshTileWalk = 0xFFFFFFFFu;
+constexpr uint32_t kMeshTileSphere = 0x80000000u;          // entry: an index into the sphere leaf arrays (a joint tree), else a filter record
 struct MeshTileLists {
     uint32_t *count;                 // [tiles]; null: no lists
     uint2 *entries;                  // [tiles][kMeshTileCap]: {filter record, bits of t_lb}
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
     __shared__ uint32_t s_idx[4][kMeshTileCap];
     __shared__ float s_tlb[4][kMeshTileCap];
     __shared__ uint32_t s_cnt[4];
-    __shared__ uint32_t s_lstart[4][64], s_lfirst[4][64];
+    __shared__ uint32_t s_lstart[4][64], s_lfirst[4][64], s_lsph[4][64];
     const SceneView &sv = *svp;
     const RowsView &rv = *rvp;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
     }
     if (__ballot(have) == 0ull) { if (lane == 0) tl.count[tile] = 0u; return; }
     double dlo[3], dhi[3], gap2 = 0.0, far2 = 0.0;
-    bool ok = (root & kBvhFlatNode) != 0u;
+    bool ok = true;
     for (int a = 0; a < 3; ++a) {
         const double lo = tmin[a] - omax[a], hi = tmax[a] - omin[a];
         const double w = (fabs(lo) + fabs(hi)) * 1e-12 + 1e-300;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
     const double A2 = 2.0 * S * (64.0 / 16777216.0) * (1.0 + 1e-6) * lmax;
 
     uint32_t *const stk = &s_stack[wv][0];
-    if (lane == 0) { s_cnt[wv] = 0u; stk[0] = root & ~kBvhFlatNode; }
+    if (lane == 0) { s_cnt[wv] = 0u; stk[0] = root; }                 // (links keep their kBvhFlatNode flag on the stack)
     __builtin_amdgcn_wave_barrier();
     uint32_t sp = 1;
     ok = __ballot(!ok) == 0ull;
@@ -339,16 +340,27 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
         __builtin_amdgcn_wave_barrier();
         bool bad = false, interior = false, leaf = false;
         uint32_t link = 0, cnt = 0xFFFFFFFFu;
+        double u_enter = 0.0;                              // where the beam can enter the child's box (the sorting bound of a sphere leaf)
         if (active) {
-            const float4 *np = nodes + 8 * (size_t)node;
-            const float4 r = np[c];                        // {lo.x, lo.y, hi.x, hi.y}
-            link = reinterpret_cast<const uint32_t *>(np + 4)[c];
-            cnt = reinterpret_cast<const uint32_t *>(np + 5)[c];
+            const bool flat = (node & kBvhFlatNode) != 0u;
+            const float4 *np = nodes + 8 * (size_t)(node & ~kBvhFlatNode);
+            double lo[3], hi[3];
+            if (flat) {                                    // a footprint node: 4 x {lo.x, lo.y, hi.x, hi.y}, the links, the counts
+                const float4 r = np[c];
+                link = reinterpret_cast<const uint32_t *>(np + 4)[c];
+                cnt = reinterpret_cast<const uint32_t *>(np + 5)[c];
+                lo[0] = (double)r.x; lo[1] = (double)r.y; hi[0] = (double)r.z; hi[1] = (double)r.w;
+                lo[2] = -__builtin_inf(); hi[2] = __builtin_inf();
+            } else {                                       // a 3-D node of a joint tree: 4 x {lo.xyz, link}, 4 x {hi.xyz, count}
+                const float4 a = np[c], b = np[4 + c];
+                link = __float_as_uint(a.w); cnt = __float_as_uint(b.w);
+                lo[0] = (double)a.x; lo[1] = (double)a.y; lo[2] = (double)a.z; hi[0] = (double)b.x; hi[1] = (double)b.y; hi[2] = (double)b.z;
+            }
             if (cnt != 0xFFFFFFFFu) {
-                const double lo[2] = { (double)r.x, (double)r.y }, hi[2] = { (double)r.z, (double)r.w };
                 double u0 = 0.0, u1 = __builtin_inf();
                 bool miss = false;
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 3; ++k) {
+                    if (lo[k] == -__builtin_inf() && hi[k] == __builtin_inf()) continue;       // unbounded along this axis
                     if (dlo[k] > 0.0) u1 = fmin(u1, (hi[k] - omin[k]) / dlo[k]);
                     else if (dlo[k] < 0.0) u0 = fmax(u0, (hi[k] - omin[k]) / dlo[k]);
                     else if (omin[k] > hi[k]) miss = true;
@@ -360,14 +372,14 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
                 else if (!(miss || u0 * (1.0 - 1e-9) > u1 * (1.0 + 1e-9) + 1e-300)) {
                     interior = cnt == 0u;
                     leaf = cnt != 0u;
-                    if (leaf && (cnt & kBvhTriLeaf) == 0u) bad = true;       // (a pure footprint tree holds triangle leaves only)
+                    u_enter = u0;
                 }
             }
         }
         // the interior children the beam enters go back to the stack
         const unsigned long long im = __ballot(interior);
         const uint32_t pos = sp + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-        if (interior) { if (pos < kMeshTileStack) stk[pos] = link & ~kBvhFlatNode; else bad = true; }
+        if (interior) { if (pos < kMeshTileStack) stk[pos] = link; else bad = true; }
         sp += (uint32_t)__builtin_popcountll(im);
         // the records of the leaves the beam enters, flattened across the lanes (a leaf holds up to 6: one lane per RECORD, not per
         // leaf -- the loads of a step's ~100 records are in flight together instead of five deep)
@@ -383,6 +395,8 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
             const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
             s_lstart[wv][lane] = incl - m;
             s_lfirst[wv][lane] = link;
+            // a sphere leaf's entries are bounded by their box: kind flag + the bits of the bound (u_enter |t - o|min), in place of a filter test
+            s_lsph[wv][lane] = (lf && (cnt & kBvhTriLeaf) == 0u) ? (0x80000000u | (__float_as_uint(fmaxf(round_down_f32_dev(u_enter * lmin * (1.0 - 1e-6) - 1e-30), 0.0f)) >> 1)) : 0u;
             __builtin_amdgcn_wave_barrier();
             for (uint32_t r = lane; r < total; r += 64u) {
                 uint32_t L = 0;                                   // the last lane whose first record is <= r (binary search: starts ascend)
@@ -390,14 +404,21 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
                 for (int step = 32; step > 0; step >>= 1)
                     if (s_lstart[wv][L + step] <= r) L += step;
                 const uint32_t rec = s_lfirst[wv][L] + (r - s_lstart[wv][L]);
+                const uint32_t sph = s_lsph[wv][L];
+                if (sph != 0u) {                                // an entry of a sphere leaf: index into the leaf arrays, kMeshTileSphere set
+                    const uint32_t k = atomicAdd(&s_cnt[wv], 1u);
+                    if (k < kMeshTileCap) { s_idx[wv][k] = rec | kMeshTileSphere; s_tlb[wv][k] = __uint_as_float((sph & 0x7FFFFFFFu) << 1); }
+                    continue;
+                }
                 const float4 A = tri_f32[2 * (size_t)rec], B = tri_f32[2 * (size_t)rec + 1];
+                const bool planar = B.z < 1.0e29f;             // a record with an (x, y) rectangle; the other planes' records pass every ray
                 Iv nv = iv_add(iv_add(iv_scale(-(double)A.x, pr[0]), iv_scale(-(double)A.y, pr[1])), iv_scale(-(double)A.z, pr[2]));
                 nv.lo += (double)A.w; nv.hi += (double)A.w;
                 const Iv anv = iv_abs(iv_widen(nv));
-                // a cheap necessary condition first (most records under the strip fail it: their plane is elsewhere in z): the hit point
+                // (planar records only) a cheap necessary condition first (most records under the strip fail it: their plane is elsewhere in z): the hit point
                 // q = p + u D has its (x, y) in the record's rectangle only for u in [u0, u1] (the slab test again, on the rectangle, in
                 // the filter's coordinates and with its allowance), and |n.(v0 - p)| = u |n.D| there -- in plain interval arithmetic
-                {
+                if (planar) {
                     const double pad = A2 / lmin + 1e-9 * S;                                   // (the allowance as a length, generously)
                     double u0 = 0.0, u1 = __builtin_inf();
                     bool miss = false;
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
                 if (!(m1x == m1x) || !(m2x == m2x) || !(m1y == m1y) || !(m2y == m2y)) { bad = true; continue; }
                 if (and_max == 0.0) continue;             // n.D = 0 at every corner: no ray of the tile has a finite distance
                 const bool mixed = nd_min < 0.0 && nd_max > 0.0;            // n.D changes sign inside the box: not affine there -- a candidate
-                const bool pass = mixed || (m1x <= 0.0 && m2x >= 0.0 && m1y <= 0.0 && m2y >= 0.0);
+                const bool pass = mixed || !planar || (m1x <= 0.0 && m2x >= 0.0 && m1y <= 0.0 && m2y >= 0.0);
                 if (!pass) continue;
                 const float t_lb = round_down_f32_dev(anv.lo * lmin / and_max * (1.0 - 1e-6));
                 const uint32_t k = atomicAdd(&s_cnt[wv], 1u);
@@ -521,6 +542,40 @@ constexpr int kPkLaneStack = 63;
                     }                                                                                                               \
                 }
 
+// One record of a sphere leaf of a joint tree against the wave's rays (bvh_traverse_spheres' bounds, rtx_traverse.h): walk and list sweep.
+#define RTX_PK_SPH_RECORD(IDX, IN)                                                                                                  \
+                {                                                                                                                   \
+                    const uint32_t e_ = (IDX);                                                                                      \
+                    const float4 rec = csph[e_];                          /* {c - centre, r} */                                     \
+                    const uint32_t prim = ma.sphere_prims[e_];                                                                      \
+                    if (IN) {                                                                                                       \
+                        const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;                                     \
+                        const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));                           \
+                        const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);\
+                        const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));                                   \
+                        const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);                                                         \
+                        const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);                                                        \
+                        const float Dp = Dl + G;                                                                                    \
+                        if (Dp >= 0.0f) {                                                                                           \
+                            const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;                      \
+                            const float Dm = Dl - G;                                                                                \
+                            const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();\
+                            if (tlo <= best_up && !(thi < 0.0f)) {                                                                  \
+                                if (tlo > sr.K) best_up = fminf(best_up, thi);                                                      \
+                                if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {                                                 \
+                                    if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;       \
+                                    else { overflow = true; best_up = -__builtin_inff(); }                                          \
+                                }                                                                                                   \
+                                if (!overflow) {                                                                                    \
+                                    lq[(size_t)qcnt * kBvhThreads + tid] = prim;                                                    \
+                                    lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);                     \
+                                    qcnt += 1;                                                                                      \
+                                }                                                                                                   \
+                            }                                                                                                       \
+                        }                                                                                                           \
+                    }                                                                                                               \
+                }
+
 // PLAIN 1: every node is a footprint node, every leaf a triangle leaf (C3, C5).  PLAIN 0: a joint tree -- 3-D nodes over
 // sphere boxes and the footprints of the other planes, the (x, y) footprint sub-tree behind links with kBvhFlatNode, sphere
 // leaves with bvh_traverse_spheres' bounds (cmax_ru: SceneView::sphere_cmax rounded up, for their error terms).
@@ -587,8 +642,8 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
             }
         }
 
-        // a pure footprint tree: the tile's list, if it has one (wave-uniform: scalar loads), instead of the walk
-        if constexpr (PLAIN != 0) {
+        // the tile's list, if it has one (wave-uniform: scalar loads), instead of the walk
+        {
             if (tl.count != nullptr && node != kNone) {
                 const uint32_t tile_of = (uint32_t)((t_next - 1ull) % (unsigned long long)tl.tiles_per_sample);
                 const uint32_t list_n = pk_const(tl.count)[tile_of];
@@ -600,7 +655,8 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
                         const bool in = walk && t_lb <= best_up;
                         if (RTX_PK_BALLOT(in) == 0ull) break;      // sorted by t_lb: nothing further can beat any lane's certain hit
                         if (in) nleaf += 1;
-                        RTX_PK_TRI_RECORD(e, in)
+                        if (!PLAIN && (e & kMeshTileSphere) != 0u) RTX_PK_SPH_RECORD(e & ~kMeshTileSphere, in)
+                        else RTX_PK_TRI_RECORD(e, in)
                     }
                     node = kNone;
                 }
@@ -644,35 +700,7 @@ __global__ __launch_bounds__(kBvhThreads, PLAIN ? kPkWaves : kPkWavesJoint) void
                 const uint32_t first = lnk[c], n = cnt[c] & 0xFFFFu;
                 if (in) nleaf += n;
                 if (!PLAIN && (cnt[c] & kBvhTriLeaf) == 0u) {         // spheres: bvh_traverse_spheres' bounds (rtx_traverse.h)
-                    for (uint32_t j = 0; j < n; ++j) {
-                        const float4 rec = csph[first + j];                          // {c - centre, r}
-                        const uint32_t prim = ma.sphere_prims[first + j];
-                        if (!in) continue;
-                        const float ox = rec.x - sr.px, oy = rec.y - sr.py, oz = rec.z - sr.pz;
-                        const float b = __builtin_fmaf(ox, sr.dx, __builtin_fmaf(oy, sr.dy, oz * sr.dz));
-                        const float lx = __builtin_fmaf(-b, sr.dx, ox), ly = __builtin_fmaf(-b, sr.dy, oy), lz = __builtin_fmaf(-b, sr.dz, oz);
-                        const float l2 = __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz));
-                        const float Dl = __builtin_fmaf(rec.w, rec.w, -l2);
-                        const float G = __builtin_fmaf(sr.Kg, rec.w, sr.c0);
-                        const float Dp = Dl + G;
-                        if (Dp >= 0.0f) {
-                            const float tlo = b - __builtin_amdgcn_sqrtf(Dp) * (1.0f + 4.76837158e-7f) - sr.K;
-                            const float Dm = Dl - G;
-                            const float thi = Dm > 0.0f ? b - __builtin_amdgcn_sqrtf(Dm) * (1.0f - 4.76837158e-7f) + sr.K : __builtin_inff();
-                            if (tlo <= best_up && !(thi < 0.0f)) {
-                                if (tlo > sr.K) best_up = fminf(best_up, thi);
-                                if (!mesh_queue_room(lq, tid, qcnt, best_up, 1u)) {
-                                    if (wf_flush_to_extra(st, (uint32_t)p, lq, kMeshQueue, tid, qcnt, best_up)) extra = true;
-                                    else { overflow = true; best_up = -__builtin_inff(); }
-                                }
-                                if (!overflow) {
-                                    lq[(size_t)qcnt * kBvhThreads + tid] = prim;
-                                    lq[(size_t)(kMeshQueue + qcnt) * kBvhThreads + tid] = __float_as_uint(tlo);
-                                    qcnt += 1;
-                                }
-                            }
-                        }
-                    }
+                    for (uint32_t j = 0; j < n; ++j) RTX_PK_SPH_RECORD(first + j, in)
                     continue;
                 }
                 for (uint32_t j = 0; j < n; ++j) RTX_PK_TRI_RECORD(first + j, in)
@@ -1242,7 +1270,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
         if (level == 0u && packets) {
             const uint32_t lane_stack = 3u * sv.bvh_depth + 2u <= (uint32_t)kPkLaneStack && (sv.tuning & RTX_TUNE_PK_LDS_STACK) == 0u ? 1u : 0u;
             MeshTileLists tl{};
-            if (!joint && tile_list_mem && (sv.tuning & RTX_TUNE_NO_TILE_LISTS) == 0u && rv.n_samples != 0u) {
+            if (tile_list_mem && (sv.tuning & RTX_TUNE_NO_TILE_LISTS) == 0u && rv.n_samples != 0u) {
                 // what each tile's primary rays can pass the filter of, once per tile (build_mesh_tile_lists_kernel)
                 const uint32_t n_tiles = (uint32_t)((rv.n_rays / rv.n_samples) >> 6);
                 tl.count = reinterpret_cast<uint32_t *>(tile_list_mem);

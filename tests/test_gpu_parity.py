@@ -908,7 +908,8 @@ def test_tile_lists_of_the_primary_rays_keep_the_bits(gpu, oracle):
 
 
 def test_tile_lists_of_a_mesh_keep_the_bits(gpu):
-    """Level 0 of a pure (x, y)-footprint tree (RTX_KERNEL_WAVEFRONT's packets): which filter records a tile's primary rays can pass
+    """Level 0 of a tree that holds triangles (RTX_KERNEL_WAVEFRONT's packets; pure (x, y)-footprint trees and joint trees with spheres and
+    faces solved in the other planes): which filter records (and spheres) a tile's primary rays can pass
     is found once per tile (build_mesh_tile_lists_kernel: the footprint tree walked with the beam's (x, y) slabs, tri_filter_sign's
     inequalities at the corners of the direction box) and every packet of the tile runs its leaf code over that list.  Same image and
     segment count as the packets' own walks (RTX_TUNE_NO_TILE_LISTS) and as the exhaustive kernel -- in particular where
@@ -919,7 +920,13 @@ def test_tile_lists_of_a_mesh_keep_the_bits(gpu):
     from rust_raytracing_amd import scenes
     mesh = scenes.light_every(scenes.random_triangles(60000, 2), 7)
     dense = scenes.light_every(scenes.compact(scenes.random_triangles(60000, 3), k=0.12, x0=6.0), 7)       # ~1000 records behind a tile
+    # a joint tree: spheres, (x, y) footprints and faces solved in the other planes -- the list holds sphere entries and filter records
+    joint = np.concatenate([scenes.random_spheres(3000, 4), scenes.light_every(scenes.random_triangles(30000, 5), 7),
+                            scenes.axis_aligned_mesh(400, seed=9, span=60.0, x0=20.0)])
     cases = [("c3 recipe", mesh, 384, 216, scenes.CAMERA, {}), ("partial tiles", mesh, 381, 211, scenes.CAMERA, {}),
+             ("joint", joint, 384, 216, scenes.CAMERA, {}), ("joint, inside", joint, 256, 144, ((60.0, 3.0, -2.0), (0.7, 0.6, 0.2), 1.3), {}),
+             ("joint, inside, down z", joint, 256, 144, ((60.0, 0.0, 30.0), (0.0, 0.0, -1.0), 1.2), {}),
+             ("joint, wide aperture", joint, 256, 144, scenes.CAMERA, dict(non_focal_offset=5.0, focal_length=30.0)),
              ("inside", mesh, 256, 144, ((60.0, 3.0, -2.0), (0.7, 0.6, 0.2), 1.3), {}),
              ("inside, along -x", mesh, 256, 144, ((60.0, 0.0, 0.0), (-1.0, 0.0, 0.0), 1.2), {}),
              ("inside, along +y", mesh, 256, 144, ((60.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1.2), {}),
@@ -949,7 +956,7 @@ def test_tile_lists_of_a_mesh_keep_the_bits(gpu):
             assert np.array_equal(a, b, equal_nan=True) and sa.segments == sb.segments, (name, other)
         assert sa.box_tests <= out["walks"][1].box_tests, name
         used += sa.box_tests < 0.8 * out["walks"][1].box_tests
-    assert used >= 6
+    assert used >= 9
     # a band of blocks
     hnd = hip_scene(gpu, mesh, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_WAVEFRONT, rays_per_pixel=2, seed=11).upload(0)
     w, h = 384, 216
