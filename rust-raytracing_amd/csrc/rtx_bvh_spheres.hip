@@ -591,105 +591,8 @@ __device__ __forceinline__ void sph_packet_walk(const PkConst4 cnodes, const PkC
 // lane's nearest certain hit.  The list is a superset of what any walk of the tile would reach (the beam contains every ray; the
 // boxes are the walk's own), the candidates' exact tests decide as before: same bits.  A tile whose list would exceed kTileListCap
 // entries (the camera inside a cluster, focal_length ~ 0, NaNs), or whose walk exceeds the builder's stack, keeps the packet walk.
-constexpr uint32_t kTileListCap = 64;                     // entries per tile
-constexpr uint32_t kTileListWalk = 0xFFFFFFFFu;           // count: this tile walks
-struct TileEntry { float4 rec; uint32_t prim; float t_lb; uint32_t pad0, pad1; };      // 32 bytes: one s_load_dwordx8
-static_assert(sizeof(TileEntry) == 32, "TileEntry");
-struct TileLists {
-    uint32_t *count;                                      // [tiles]; null: no lists (every tile walks)
-    TileEntry *entries;                                   // [tiles][kTileListCap]
-};
-
-__global__ __launch_bounds__(256) void build_tile_lists_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
-                                                               const float4 *__restrict__ nodes, const float4 *__restrict__ sphere_f32,
-                                                               const uint32_t *__restrict__ sphere_prims, TileLists tl, uint32_t n_tiles)
-{
-    const SceneView &sv = *svp;
-    const RowsView &rv = *rvp;
-    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= n_tiles) return;
-    // ---- the beam: O, T (the hull of the tile's pixels that exist), D = T - O outward-rounded, the shortest |t - o|
-    const double nfo = sv.non_focal_offset, fo = sv.focal_offset;
-    const double cam[3] = { sv.cam_pos.x, sv.cam_pos.y, sv.cam_pos.z };
-    double omin[3], omax[3], tmin[3], tmax[3];
-    for (int a = 0; a < 3; ++a) {
-        omin[a] = cam[a] + fmin(0.0, nfo); omax[a] = cam[a] + fmax(0.0, nfo);     // rnd in [0, 1): monotone roundings keep the bounds
-        tmin[a] = __builtin_inf(); tmax[a] = -__builtin_inf();
-    }
-    bool any = false;
-    for (uint32_t j = 0; j < 64u; ++j) {
-        uint32_t pl, smp;
-        if (!ray_index_to_pixel_tiled(rv, (uint64_t)tile * 64u + j, pl, smp)) continue;
-        const V3 f = primary_focal_point(sv, rv, pl);
-        const double fp[3] = { f.x, f.y, f.z };
-        for (int a = 0; a < 3; ++a) {
-            tmin[a] = fmin(tmin[a], fp[a] + fmin(0.0, fo));
-            tmax[a] = fmax(tmax[a], fp[a] + fmax(0.0, fo));
-        }
-        any = true;
-    }
-    if (!any) { tl.count[tile] = 0u; return; }            // (a tile of padding only: no ray looks at it)
-    double dlo[3], dhi[3], gap2 = 0.0;
-    bool ok = true;
-    for (int a = 0; a < 3; ++a) {
-        const double lo = tmin[a] - omax[a], hi = tmax[a] - omin[a];
-        const double w = (fabs(lo) + fabs(hi)) * 1e-12 + 1e-300;
-        dlo[a] = lo - w; dhi[a] = hi + w;
-        const double g = fmax(0.0, fmax(tmin[a] - omax[a], omin[a] - tmax[a]));
-        gap2 += g * g;
-        ok = ok && isfinite(dlo[a]) && isfinite(dhi[a]) && isfinite(omin[a]) && isfinite(omax[a]);
-    }
-    const double lmin = sqrt(gap2) * (1.0 - 1e-9);
-    ok = ok && (sv.bvh_root & kBvhFlatNode) == 0u;
-    // ---- the walk: every leaf box the beam can enter
-    TileEntry *const out = tl.entries + (size_t)tile * kTileListCap;
-    uint32_t stack[64];
-    uint32_t sp = 0, n = 0, node = sv.bvh_root;
-    while (ok && node != 0xFFFFFFFFu) {
-        const float4 *np = nodes + 8 * (size_t)node;
-        node = 0xFFFFFFFFu;
-        for (int c = 0; c < 4 && ok; ++c) {
-            const float4 a = np[c], b = np[4 + c];
-            const uint32_t link = __float_as_uint(a.w), cnt = __float_as_uint(b.w);
-            if (cnt == 0xFFFFFFFFu) continue;             // an empty slot
-            const double lo[3] = { (double)a.x, (double)a.y, (double)a.z }, hi[3] = { (double)b.x, (double)b.y, (double)b.z };
-            double u0 = 0.0, u1 = __builtin_inf();
-            bool miss = false;
-            for (int k = 0; k < 3; ++k) {
-                // omin + u dlo <= hi
-                if (dlo[k] > 0.0) u1 = fmin(u1, (hi[k] - omin[k]) / dlo[k]);
-                else if (dlo[k] < 0.0) u0 = fmax(u0, (hi[k] - omin[k]) / dlo[k]);
-                else if (omin[k] > hi[k]) miss = true;
-                // omax + u dhi >= lo
-                if (dhi[k] > 0.0) u0 = fmax(u0, (lo[k] - omax[k]) / dhi[k]);
-                else if (dhi[k] < 0.0) u1 = fmin(u1, (lo[k] - omax[k]) / dhi[k]);
-                else if (omax[k] < lo[k]) miss = true;
-            }
-            if (!(u0 == u0) || !(u1 == u1)) { ok = false; break; }          // NaN (inf - inf, 0 / 0): no list for this tile
-            if (miss || u0 * (1.0 - 1e-9) > u1 * (1.0 + 1e-9) + 1e-300) continue;
-            if (cnt == 0u) {                              // interior child
-                if (sp == 64u) { ok = false; break; }
-                stack[sp++] = link;
-            } else if ((cnt & kBvhTriLeaf) == 0u) {       // sphere leaf: `cnt` records from `link`
-                const float t_lb = round_down_f32_dev(u0 * lmin * (1.0 - 1e-6) - 1e-30);
-                for (uint32_t j = 0; j < (cnt & 0xFFFFu); ++j) {
-                    if (n == kTileListCap) { ok = false; break; }
-                    // insertion by t_lb (ascending; equal bounds keep their order of arrival)
-                    uint32_t k = n;
-                    while (k > 0u && out[k - 1u].t_lb > t_lb) { out[k] = out[k - 1u]; --k; }
-                    TileEntry e;
-                    e.rec = sphere_f32[link + j]; e.prim = sphere_prims[link + j]; e.t_lb = t_lb; e.pad0 = e.pad1 = 0u;
-                    out[k] = e;
-                    ++n;
-                }
-            } else {
-                ok = false;                               // (a sphere tree holds no triangle leaves)
-            }
-        }
-        if (ok && sp != 0u) node = stack[--sp];
-    }
-    tl.count[tile] = ok ? n : kTileListWalk;
-}
+// (kTileListCap, TileEntry, TileLists: rtx_launch.h; the builder is the wave-per-tile kernel of rtx_wavefront.hip, which also serves
+//  the meshes' lists: launch_build_sphere_tile_lists)
 
 __global__ __launch_bounds__(kBvhThreads, kSpkWaves) void trace_sph_packet_kernel(const SceneView *__restrict__ svp,
                                                                                   const RowsView *__restrict__ rvp,
@@ -995,9 +898,7 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
             const uint32_t n_tiles = (uint32_t)((rv.n_rays / rv.n_samples) >> 6);
             tl.count = reinterpret_cast<uint32_t *>(tile_list_mem);
             tl.entries = reinterpret_cast<TileEntry *>(static_cast<char *>(tile_list_mem) + (((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255));
-            hipLaunchKernelGGL(build_tile_lists_kernel, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, d_sv, d_rv, nodes, la.sphere_f32,
-                               la.sphere_prims, tl, n_tiles);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = launch_build_sphere_tile_lists(d_sv, d_rv, sv, n_tiles, tl.count, tl.entries, stream)) != hipSuccess) return e;
         }
         hipLaunchKernelGGL(trace_sph_packet_kernel, dim3(pblocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
                            nodes, la, sq, tl);

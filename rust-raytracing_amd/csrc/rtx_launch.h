@@ -41,6 +41,19 @@ size_t bvh_spheres_spill_bytes(const SceneView &sv, int n_cus);
 // cannot take raises counters[1].pad_ (the launch's watchdog word, reported by the API).
 size_t bvh_spheres_queue_bytes(uint64_t n_rays, int n_cus);
 size_t bvh_spheres_tile_list_bytes(uint64_t rays_per_sample);
+// The tile lists of a sphere tree (rtx_bvh_spheres.hip, "Tile lists"): per tile a count (kTileListWalk: this tile walks) and up to
+// kTileListCap entries {the leaf's f32 record, its index, a lower bound of the distance at which any ray of the tile can enter its box},
+// 32 bytes each -- one s_load_dwordx8 in the packet kernel.  Built by the wave-per-tile builder of rtx_wavefront.hip.
+constexpr uint32_t kTileListCap = 64;
+constexpr uint32_t kTileListWalk = 0xFFFFFFFFu;
+struct TileEntry { float4 rec; uint32_t prim; float t_lb; uint32_t pad0, pad1; };
+static_assert(sizeof(TileEntry) == 32, "TileEntry");
+struct TileLists {
+    uint32_t *count;                                      // [tiles]; null: no lists (every tile walks)
+    TileEntry *entries;                                   // [tiles][kTileListCap]
+};
+hipError_t launch_build_sphere_tile_lists(const SceneView *d_sv, const RowsView *d_rv, const SceneView &sv, uint32_t n_tiles, uint32_t *count,
+                                          TileEntry *entries, hipStream_t stream);
 // may a launch run in two stages?  The product's stage 1 exists as packets only (tiled ray queue, a tree the wave-uniform stack
 // holds); the lab library falls back to per-lane primary rays (MODE 1) and always may.
 bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled);

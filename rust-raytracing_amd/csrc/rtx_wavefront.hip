@@ -276,8 +276,12 @@ __device__ __forceinline__ double wave_max_f64(double v)
 // plain interval arithmetic over D loses (a record 100 units away would be accepted +- 2 units around its true footprint).
 __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
                                                                     const float4 *__restrict__ nodes, const float4 *__restrict__ tri_f32,
-                                                                    MeshTileLists tl, uint32_t n_tiles, uint32_t root)
+                                                                    MeshTileLists tl, uint32_t n_tiles, uint32_t root, uint32_t cap,
+                                                                    TileEntry *__restrict__ sph_out, const float4 *__restrict__ sphere_f32,
+                                                                    const uint32_t *__restrict__ sphere_prims)
 {
+    // cap <= kMeshTileCap: entries a tile's list may hold.  sph_out != null (a sphere tree: every entry is a sphere): the list is
+    // written in the sphere packets' format -- TileEntry {record, index, bound} -- instead of {entry, bound} pairs
     __shared__ uint32_t s_stack[4][kMeshTileStack];
     __shared__ uint32_t s_idx[4][kMeshTileCap];
     __shared__ float s_tlb[4][kMeshTileCap];
@@ -465,13 +469,14 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
             __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
-        ok = __ballot(bad) == 0ull && s_cnt[wv] <= kMeshTileCap;
+        ok = __ballot(bad) == 0ull && s_cnt[wv] <= cap;
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t n = s_cnt[wv];
-    if (!ok || n > kMeshTileCap) { if (lane == 0) tl.count[tile] = kMeshTileWalk; return; }
+    if (!ok || n > cap) { if (lane == 0) tl.count[tile] = kMeshTileWalk; return; }
     // rank sort by t_lb (ties: the order of arrival) into the tile's list
     uint2 *const out = tl.entries + (size_t)tile * kMeshTileCap;
+    TileEntry *const sout = sph_out ? sph_out + (size_t)tile * cap : nullptr;
     for (uint32_t e = lane; e < n; e += 64u) {
         const float te = s_tlb[wv][e];
         uint32_t rank = 0;
@@ -479,7 +484,14 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
             const float tg = s_tlb[wv][g];
             rank += (tg < te || (tg == te && g < e)) ? 1u : 0u;
         }
-        out[rank] = make_uint2(s_idx[wv][e], __float_as_uint(te));
+        if (sout) {
+            const uint32_t li = s_idx[wv][e] & ~kMeshTileSphere;
+            TileEntry t;
+            t.rec = sphere_f32[li]; t.prim = sphere_prims[li]; t.t_lb = te; t.pad0 = t.pad1 = 0u;
+            sout[rank] = t;
+        } else {
+            out[rank] = make_uint2(s_idx[wv][e], __float_as_uint(te));
+        }
     }
     if (lane == 0) tl.count[tile] = n;
 }
@@ -1198,6 +1210,19 @@ size_t wavefront_spill_bytes(const SceneView &sv, int n_cus)
     return std::max(own, bvh_mesh_spill_bytes(sv, n_cus));
 }
 
+// the same builder for a sphere tree (its nodes are 3-D, its leaves sphere leaves): lists in the sphere packets' format
+hipError_t launch_build_sphere_tile_lists(const SceneView *d_sv, const RowsView *d_rv, const SceneView &sv, uint32_t n_tiles, uint32_t *count,
+                                          TileEntry *entries, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    MeshTileLists tl{};
+    tl.count = count; tl.entries = nullptr; tl.tiles_per_sample = n_tiles;
+    hipLaunchKernelGGL(build_mesh_tile_lists_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream, d_sv, d_rv,
+                       reinterpret_cast<const float4 *>(sv.bvh_nodes), (const float4 *)nullptr, tl, n_tiles, sv.bvh_root, kTileListCap, entries,
+                       sv.bvh_leaf_cr, sv.bvh_prims);
+    return hipGetLastError();
+}
+
 size_t wavefront_tile_list_bytes(uint64_t rays_per_sample)
 {
     const uint64_t n_tiles = rays_per_sample >> 6;
@@ -1277,7 +1302,7 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
                 tl.entries = reinterpret_cast<uint2 *>(static_cast<char *>(tile_list_mem) + (((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255));
                 tl.tiles_per_sample = n_tiles;
                 hipLaunchKernelGGL(build_mesh_tile_lists_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream, d_sv, d_rv, nodes, ma.tri_f32, tl,
-                                   n_tiles, sv.bvh_root);
+                                   n_tiles, sv.bvh_root, kMeshTileCap, (TileEntry *)nullptr, (const float4 *)nullptr, (const uint32_t *)nullptr);
             }
             if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack, tl);
             else hipLaunchKernelGGL(wf_trace_packet_kernel<1>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack, tl);
