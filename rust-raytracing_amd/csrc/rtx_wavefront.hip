@@ -254,6 +254,9 @@ __device__ __forceinline__ Iv iv_mul(Iv a, Iv b)
 __device__ __forceinline__ Iv iv_widen(Iv a) { const double w = (fabs(a.lo) + fabs(a.hi)) * 1e-12 + 1e-300; return Iv{a.lo - w, a.hi + w}; }
 
 constexpr uint32_t kMeshTileStack = 512;                     // the builder's node stack per wave (LDS)
+constexpr uint32_t kMeshTileBudget = 32768;                  // records + node children a tile's build may look at before it gives up (the tile
+                                                             // then walks): a wide beam in a dense mesh would test everything under it only to
+                                                             // overflow at the end -- C5's tiles at 4K look at ~12 000
 
 __device__ __forceinline__ double wave_min_f64(double v)
 {
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
     uint32_t *const stk = &s_stack[wv][0];
     if (lane == 0) { s_cnt[wv] = 0u; stk[0] = root; }                 // (links keep their kBvhFlatNode flag on the stack)
     __builtin_amdgcn_wave_barrier();
-    uint32_t sp = 1;
+    uint32_t sp = 1, looked = 0;
     ok = __ballot(!ok) == 0ull;
     while (ok && sp != 0u) {
         const uint32_t take = sp < 16u ? sp : 16u;
@@ -397,6 +400,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
                 if ((int)lane >= off) incl += t;
             }
             const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            looked += total + 4u * take;
             s_lstart[wv][lane] = incl - m;
             s_lfirst[wv][lane] = link;
             // a sphere leaf's entries are bounded by their box: kind flag + the bits of the bound (u_enter |t - o|min), in place of a filter test
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneV
             __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
-        ok = __ballot(bad) == 0ull && s_cnt[wv] <= cap;
+        ok = __ballot(bad) == 0ull && s_cnt[wv] <= cap && looked <= kMeshTileBudget;
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t n = s_cnt[wv];
