@@ -1052,7 +1052,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                    h->n_cus, k == 0 ? h->wf_state : b.queue, sph_flags, st,
                                                    stats ? (k == 0 ? h->counters_stage1 : b.counters_stage1) : nullptr,
                                                    stats ? (k == 0 ? h->ev[3] : b.stage1_done) : nullptr, nullptr, nullptr,
-                                                   nullptr));                   // (the halves' packets walk: no tile lists in this form)
+                                                   nullptr, false));            // (the halves' packets walk: no tile lists in this form)
         }
         RTX_HIP_CHECK(hipEventRecord(b.join, b.stream));
         RTX_HIP_CHECK(hipStreamWaitEvent(stream, b.join, 0));
@@ -1107,7 +1107,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
 #endif
                 RTX_HIP_CHECK(launch_trace_wavefront(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->wf_state, h->counters,
                                                      reinterpret_cast<uint32_t *>(h->state), h->n_cus, stream,
-                                                     wf_mesh && tile_list_bytes != 0 ? h->tile_lists : nullptr));
+                                                     wf_mesh && tile_list_bytes != 0 ? h->tile_lists : nullptr, s0 == 0));   // (a frame's later sample batches reuse its lists)
         } else if (kernel == RTX_KERNEL_BVH_REGROUP) {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
 #ifdef RTX_LAB
@@ -1135,7 +1135,7 @@ static int32_t render_band(RtxSceneHandle h, uint32_t width, uint32_t height, ui
                                                        stats && spheres_two_stage ? h->counters_stage1 : nullptr,
                                                        stats && spheres_two_stage ? h->ev[3] : nullptr, spheres_two_stage && (tuning & (RTX_TUNE_STAGE2_POOL | RTX_TUNE_STAGE2_PAIR)) ? h->pool : nullptr,
                                                        stage2_slots ? h->slots : nullptr,
-                                                       spheres_two_stage && tile_list_bytes != 0 ? h->tile_lists : nullptr));
+                                                       spheres_two_stage && tile_list_bytes != 0 ? h->tile_lists : nullptr, s0 == 0));
         } else {
             RTX_HIP_CHECK(hipMemsetAsync(h->work_counter, 0, sizeof(unsigned long long), stream));
             RTX_HIP_CHECK(launch_trace_mixed(h->d_sv, h->sv, h->d_rv, rv, h->samples, h->state, h->counters, h->work_counter, h->n_cus,

@@ -833,7 +833,7 @@ bool bvh_spheres_two_stage_ok(const SceneView &sv, bool tiled)
 hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot, hipEvent_t stage1_done,
-                                    void *pool_mem, void *slots_mem, void *tile_list_mem)
+                                    void *pool_mem, void *slots_mem, void *tile_list_mem, bool build_tile_lists)
 {
     const uint64_t want = (rv.n_rays + kBvhThreads - 1) / kBvhThreads;
     const uint64_t cap = (uint64_t)n_cus * kSphWavesPerSimd;
@@ -898,7 +898,7 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
             const uint32_t n_tiles = (uint32_t)((rv.n_rays / rv.n_samples) >> 6);
             tl.count = reinterpret_cast<uint32_t *>(tile_list_mem);
             tl.entries = reinterpret_cast<TileEntry *>(static_cast<char *>(tile_list_mem) + (((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255));
-            if ((e = launch_build_sphere_tile_lists(d_sv, d_rv, sv, n_tiles, tl.count, tl.entries, stream)) != hipSuccess) return e;
+            if (build_tile_lists && (e = launch_build_sphere_tile_lists(d_sv, d_rv, sv, n_tiles, tl.count, tl.entries, stream)) != hipSuccess) return e;
         }
         hipLaunchKernelGGL(trace_sph_packet_kernel, dim3(pblocks), dim3(kBvhThreads), 0, stream, d_sv, d_rv, samples, counters, work_counter,
                            nodes, la, sq, tl);

@@ -61,7 +61,8 @@ hipError_t launch_trace_bvh_spheres(const SceneView *d_sv, const SceneView &sv, 
                                     double *samples, Counters *counters, unsigned long long *work_counter, uint32_t *spill, int n_cus,
                                     void *queue_mem, uint32_t flags, hipStream_t stream, Counters *stage1_snapshot = nullptr,
                                     hipEvent_t stage1_done = nullptr, void *pool_mem = nullptr, void *slots_mem = nullptr,
-                                    void *tile_list_mem = nullptr);      // tile_list_mem: bvh_spheres_tile_list_bytes(rays per sample) bytes, or null: every tile walks
+                                    void *tile_list_mem = nullptr, bool build_tile_lists = true);      // tile_list_mem: bvh_spheres_tile_list_bytes(rays per sample) bytes, or null: every tile walks;
+                                    // build_tile_lists false: the lists of an earlier launch of the same frame (another sample batch) are still in it
 #ifdef RTX_LAB
 // slots_mem: bvh_spheres_slots_bytes(n_cus) bytes of device memory, or null: with it stage 2 of the two-stage form runs over ray
 // slots (trace_sph_slots_kernel: the f64 path state of the rays in flight, one 128-byte record per slot)
@@ -121,7 +122,7 @@ uint32_t wavefront_levels(const SceneView &sv);
 size_t wavefront_spill_bytes(const SceneView &sv, int n_cus);
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                   double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream,
-                                  void *tile_list_mem = nullptr);      // wavefront_tile_list_bytes(rays per sample) bytes, or null: every tile walks
+                                  void *tile_list_mem = nullptr, bool build_tile_lists = true);      // wavefront_tile_list_bytes(rays per sample) bytes, or null: every tile walks
 size_t wavefront_tile_list_bytes(uint64_t rays_per_sample);
 
 #ifdef RTX_LAB       // librtx_hip_lab.so only

@@ -1235,7 +1235,7 @@ size_t wavefront_tile_list_bytes(uint64_t rays_per_sample)
 
 hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, const RowsView *d_rv, const RowsView &rv,
                                   double *samples, void *state_mem, Counters *counters, uint32_t *spill, int n_cus, hipStream_t stream,
-                                  void *tile_list_mem)
+                                  void *tile_list_mem, bool build_tile_lists)
 {
     if (rv.n_rays == 0) return hipSuccess;
     const uint32_t levels = wavefront_levels(sv);
@@ -1305,7 +1305,8 @@ hipError_t launch_trace_wavefront(const SceneView *d_sv, const SceneView &sv, co
                 tl.count = reinterpret_cast<uint32_t *>(tile_list_mem);
                 tl.entries = reinterpret_cast<uint2 *>(static_cast<char *>(tile_list_mem) + (((size_t)n_tiles * sizeof(uint32_t) + 255) & ~(size_t)255));
                 tl.tiles_per_sample = n_tiles;
-                hipLaunchKernelGGL(build_mesh_tile_lists_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream, d_sv, d_rv, nodes, ma.tri_f32, tl,
+                if (build_tile_lists)
+                    hipLaunchKernelGGL(build_mesh_tile_lists_kernel, dim3((n_tiles + 3u) / 4u), dim3(256), 0, stream, d_sv, d_rv, nodes, ma.tri_f32, tl,
                                    n_tiles, sv.bvh_root, kMeshTileCap, (TileEntry *)nullptr, (const float4 *)nullptr, (const uint32_t *)nullptr);
             }
             if (joint) hipLaunchKernelGGL(wf_trace_packet_kernel<0>, dim3(packet_blocks), dim3(kBvhThreads), 0, stream, sk, counters, nodes, ma, sv.bvh_root, cmax_ru, lane_stack, tl);

@@ -894,6 +894,18 @@ def test_tile_lists_of_the_primary_rays_keep_the_bits(gpu, oracle):
         if name == "dense":
             assert sa.stage1_box_tests > 0.5 * out["walks"][1].stage1_box_tests          # (its tiles walk: the lists overflowed)
     assert used >= 6
+    # several sample batches of one frame (a scratch cap): the lists are built with the first and reused by the others
+    out = {}
+    for tag, tune in (("lists", T), ("walks", T | gpu.RTX_TUNE_NO_TILE_LISTS)):
+        hnd = hip_scene(gpu, sparse, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=24, seed=5, tuning=tune).upload(0)
+        hnd.set_scratch_limit(300 << 20)
+        buf = torch.zeros((288, 512, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(512, 288, 0, 1, 288, buf.data_ptr())
+        hnd.close()
+        out[tag] = (buf.cpu().numpy(), st)
+    assert out["lists"][1].trace_launches >= 2 and out["walks"][1].trace_launches >= 2          # (the lists come off the cap: 3 and 2)
+    assert np.array_equal(out["lists"][0], out["walks"][0]) and out["lists"][1].segments == out["walks"][1].segments
+    assert out["lists"][1].stage1_box_tests < 0.5 * out["walks"][1].stage1_box_tests
     # a band of blocks on a caller's stream
     hnd = hip_scene(gpu, sparse, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_AUTO, rays_per_pixel=2, seed=11, tuning=T).upload(0)
     w, h = 512, 288
@@ -957,6 +969,18 @@ def test_tile_lists_of_a_mesh_keep_the_bits(gpu):
         assert sa.box_tests <= out["walks"][1].box_tests, name
         used += sa.box_tests < 0.8 * out["walks"][1].box_tests
     assert used >= 9
+    # several sample batches of one frame (a scratch cap): the lists are built with the first and reused by the others
+    out = {}
+    for tag, tune in (("lists", 0), ("walks", gpu.RTX_TUNE_NO_TILE_LISTS)):
+        hnd = hip_scene(gpu, mesh, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_WAVEFRONT, rays_per_pixel=6, seed=5, tuning=tune).upload(0)
+        hnd.set_scratch_limit(96 << 20)
+        buf = torch.zeros((216, 384, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(384, 216, 0, 1, 216, buf.data_ptr())
+        hnd.close()
+        out[tag] = (buf.cpu().numpy(), st)
+    assert out["lists"][1].trace_launches >= 2 and out["walks"][1].trace_launches >= 2
+    assert np.array_equal(out["lists"][0], out["walks"][0]) and out["lists"][1].segments == out["walks"][1].segments
+    assert out["lists"][1].box_tests < 0.8 * out["walks"][1].box_tests
     # a band of blocks
     hnd = hip_scene(gpu, mesh, cam=scenes.CAMERA, kernel=gpu.RTX_KERNEL_WAVEFRONT, rays_per_pixel=2, seed=11).upload(0)
     w, h = 384, 216
