@@ -253,6 +253,9 @@ __device__ __forceinline__ Iv iv_mul(Iv a, Iv b)
 }
 __device__ __forceinline__ Iv iv_widen(Iv a) { const double w = (fabs(a.lo) + fabs(a.hi)) * 1e-12 + 1e-300; return Iv{a.lo - w, a.hi + w}; }
 
+#ifndef RTX_TILE_BUILD_WAVES
+#define RTX_TILE_BUILD_WAVES 3
+#endif
 constexpr uint32_t kMeshTileStack = 512;                     // the builder's node stack per wave (LDS)
 constexpr uint32_t kMeshTileBudget = 32768;                  // records + node children a tile's build may look at before it gives up (the tile
                                                              // then walks): a wide beam in a dense mesh would test everything under it only to
@@ -277,7 +280,7 @@ __device__ __forceinline__ double wave_max_f64(double v)
 // origin and fixed signs of n.D and n.(v0 - p) they are affine in each component of D, so their extremes over the box sit at its
 // corners) with the origin as an interval: the dependency between a hit point and the direction that leads to it survives, which
 // plain interval arithmetic over D loses (a record 100 units away would be accepted +- 2 units around its true footprint).
-__global__ __launch_bounds__(256) void build_mesh_tile_lists_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
+__global__ __launch_bounds__(256, RTX_TILE_BUILD_WAVES) void build_mesh_tile_lists_kernel(const SceneView *__restrict__ svp, const RowsView *__restrict__ rvp,
                                                                     const float4 *__restrict__ nodes, const float4 *__restrict__ tri_f32,
                                                                     MeshTileLists tl, uint32_t n_tiles, uint32_t root, uint32_t cap,
                                                                     TileEntry *__restrict__ sph_out, const float4 *__restrict__ sphere_f32,
