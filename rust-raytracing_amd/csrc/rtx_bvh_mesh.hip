@@ -482,7 +482,9 @@ static hipError_t launch_mesh(const SceneView *d_sv, const SceneView &sv, const 
     // faces from the queue: 222 ms at 16, 233 at 32)
     const uint32_t thresh = [&] {
         const uint32_t t = (sv.tuning >> RTX_TUNE_THRESH_SHIFT) & 127u;
-        long v = t ? (long)t : (src && (sv.bvh_flags & 4u) != 0u ? 2 * RTX_BVH_MESH_THRESH : RTX_BVH_MESH_THRESH);
+        // (a joint tree from the queue, re-measured in round 4 with level 0 over tile lists: J1 16 / 24 / 32: 39.1 / 36.7 / 36.7 ms; 240k
+        //  axis-aligned faces + 2k spheres 16 / 20 / 24 / 32: 181 / 178 / 178 / 182; the faces alone 16 / 24: 160 / 164 -> 24)
+        long v = t ? (long)t : (src ? ((sv.bvh_flags & 4u) != 0u ? 2 * RTX_BVH_MESH_THRESH : (3 * RTX_BVH_MESH_THRESH) / 2) : RTX_BVH_MESH_THRESH);
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     LeafArrays la;
