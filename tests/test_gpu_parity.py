@@ -994,6 +994,58 @@ def test_tile_lists_of_a_mesh_keep_the_bits(gpu):
     hnd.close()
 
 
+def test_fuzz_tile_lists_against_the_exhaustive_kernel(gpu):
+    """Random scenes, cameras and lenses through the paths that use tile lists: 200 sphere clouds (two stages forced), 200 triangle
+    meshes and 100 joint scenes (RTX_KERNEL_WAVEFRONT) -- sizes, densities and radii over two decades, the camera anywhere from deep
+    inside to far outside looking anywhere, focal lengths of both signs, apertures from none to wider than the scene's spacing --
+    against the exhaustive f64 kernel: image and segment count bit for bit."""
+    import torch
+    from rust_raytracing_amd import scenes
+    rng = np.random.default_rng(20251005)
+
+    def render(objs, cam, kern, tune, lens, w, h):
+        hnd = hip_scene(gpu, objs, cam=cam, kernel=kern, rays_per_pixel=2, tuning=tune, **lens).upload(0)
+        buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+        st = hnd.render_rows(w, h, 0, 1, h, buf.data_ptr())
+        hnd.close()
+        return buf.cpu().numpy(), st
+
+    used = 0
+    for it in range(500):
+        kind = "spheres" if it < 200 else ("mesh" if it < 400 else "joint")
+        n = int(10 ** rng.uniform(1.7, 3.6))
+        k = float(10 ** rng.uniform(-1.3, 0.0))                       # how far the recipe's cloud is pulled together
+        if kind == "spheres":
+            objs = scenes.random_spheres(n, 100 + it)
+            objs["geom"][:, 3] *= float(10 ** rng.uniform(-0.7, 0.7))
+        elif kind == "mesh":
+            objs = scenes.light_every(scenes.random_triangles(n, 100 + it), 5)
+        else:
+            objs = np.concatenate([scenes.random_spheres(max(n // 8, 6), 100 + it), scenes.light_every(scenes.random_triangles(n, 300 + it), 5),
+                                   scenes.axis_aligned_mesh(max(n // 60, 2), seed=it, span=60.0, x0=20.0)])
+        objs = scenes.compact(objs, k=k, x0=float(rng.uniform(2.0, 12.0)))
+        centre = np.array([objs["geom"][:, 0].mean(), 0.0, 0.0])
+        where = rng.random()
+        pos = centre + rng.normal(size=3) * (3.0 * k * 40 if where < 0.5 else (60.0 * k * 40 if where < 0.8 else 0.3))
+        if where >= 0.8 and rng.random() < 0.5:
+            pos = np.zeros(3)
+        look = (centre - pos) if rng.random() < 0.6 else rng.normal(size=3)
+        if not np.any(look):
+            look = np.array([1.0, 0.0, 0.0])
+        cam = (tuple(pos), tuple(look), float(rng.uniform(0.3, 2.2)))
+        lens = dict(seed=it, focal_length=float(rng.choice([10.0, 3.0, 40.0, -5.0])), focal_offset=float(rng.choice([1e-4, 0.0, 0.05])),
+                    non_focal_offset=float(rng.choice([0.1, 0.0, 1.5, -0.3])), max_bounces=int(rng.choice([1, 4, 10])))
+        w, h = int(rng.choice([96, 101, 160])), int(rng.choice([64, 59, 88]))
+        kern, tune = (gpu.RTX_KERNEL_AUTO, gpu.RTX_TUNE_TWO_STAGE) if kind == "spheres" else (gpu.RTX_KERNEL_WAVEFRONT, 0)
+        a, sa = render(objs, cam, kern, tune, lens, w, h)
+        e, se = render(objs, cam, gpu.RTX_KERNEL_EXACT, 0, lens, w, h)
+        assert np.array_equal(a, e, equal_nan=True) and sa.segments == se.segments, (it, kind, n, cam, lens)
+        b, sb = render(objs, cam, kern, tune | gpu.RTX_TUNE_NO_TILE_LISTS, lens, w, h)
+        assert np.array_equal(a, b, equal_nan=True)
+        used += sa.box_tests < 0.9 * sb.box_tests
+    assert used >= 200
+
+
 def test_product_fallback_for_a_sphere_tree_without_64_byte_nodes(gpu):
     """The product library holds the sphere kernels in their 64-byte-node instances only.  A sphere tree whose nodes have no such
     form (coordinates beyond the quantisation's exact range: |origin / step| + 256 >= 2^24) renders with the LDS sweep under every
